@@ -1,0 +1,52 @@
+"""Loaders for the committed fixtures under tests/golden/ (see make_goldens.py)."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> (N, M_fea, P) exactly as the reference's testbench / notebooks configure them
+# (main_float.cpp:40-111, mmult-master.ipynb cells 4-6)
+SHAPES = {
+    "test": (4, 4, 2),
+    "test2": (4, 4, 2),
+    "mol": (2273, 7, 64),
+    "cora": (2708, 1433, 64),
+    "citeseer": (3327, 3703, 21),
+}
+
+
+def load(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    d = {k: g[k] for k in g.files}
+    if name in SHAPES:
+        N, M, P = SHAPES[name]
+        d["N"], d["M_fea"], d["P"] = N, M, P
+        d["w"] = np.ascontiguousarray(d["w"][:M, :P])          # loaders read M_fea lines only
+        d["Wt"] = np.ascontiguousarray(d["w"].T)              # [P][M_fea], what goes into B
+        d["adj"] = (d["adj_rowptr"], d["adj_col"], d["adj_val"])
+        d["fea"] = (d["fea_rowptr"], d["fea_col"], d["fea_val"])
+    return d
+
+
+def known_answers():
+    with open(os.path.join(GOLD, "known_answers.json")) as f:
+        return json.load(f)
+
+
+def csr_to_dense(csr, shape):
+    rp, ci, va = csr
+    out = np.zeros(shape, dtype=np.float32)
+    for r in range(shape[0]):
+        for e in range(rp[r], rp[r + 1]):
+            out[r, ci[e]] += va[e]
+    return out
+
+
+def half_ulp_distance(a, b):
+    """|a-b| in units of binary16 ulps (monotone integer mapping of the bit patterns)."""
+    def key(x):
+        u = np.asarray(x, dtype=np.float16).view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u)
+    return np.abs(key(a) - key(b))
