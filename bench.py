@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Headline benchmark: edges aggregated per second (+ achieved HBM GB/s) of a 2-layer GCN forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s100m|s100m-rmat|reddit|cora]
+
+A "step" is one 2-layer forward over one synthetic graph already resident in HBM:
+    layer 1:  D1 = relu(A . (X . W1))    X sparse CSR (gemm_mode 0), F_in -> hidden
+    layer 2:  D2 =      A . (D1 . W2)    X dense      (gemm_mode 1), hidden -> hidden
+through sgx_layer_forward (the drop-in for mmult_top).  Default workload = the configuration
+BASELINE.json's target is quoted on: S-100M -- N = 2^22 nodes, 100 M uniformly random directed
+edges (+ self loops, coalesced), GCN symmetric normalisation, fp16, hidden = 64, Cora-like
+sparse input features (F_in = 1433, density 1.27 %).  Output: ONE JSON line on rank 0.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns
+2^22 rows / 100 M edges of a graph with N * 2^22 nodes; per layer H = X.W is exchanged with one
+RCCL all-gather over xGMI and aggregated locally (sgracex1_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (log2 N or N, edges, F_in, hidden, generator, feature density)
+    "s100m": dict(n=1 << 22, edges=100_000_000, f_in=1433, hidden=64, gen="uniform", x_density=0.0127),
+    "s100m-rmat": dict(n=1 << 22, edges=100_000_000, f_in=1433, hidden=64, gen="rmat", x_density=0.0127),
+    "reddit": dict(n=232_965, edges=114_600_000, f_in=602, hidden=128, gen="uniform", x_density=None),
+    "small": dict(n=1 << 16, edges=1_000_000, f_in=256, hidden=64, gen="uniform", x_density=0.05),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="s100m", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frac", type=float, default=0.25)
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="rocprofv3 --pmc result for the dominant kernel (HBM bytes per launch)")
+    return ap.parse_args()
+
+
+def make_inputs(torch, graphs, ops, wl, rank, world, device):
+    """Synthetic graph + features + weights of the stated shape, generated on the device."""
+    n, hidden, f_in = wl["n"], wl["hidden"], wl["f_in"]
+    seed = 12345 + rank
+    n_global = n * world
+    if world == 1:
+        if wl["gen"] == "rmat":
+            A = graphs.rmat_graph(n.bit_length() - 1, wl["edges"], seed=seed, device=device)
+        else:
+            A = graphs.uniform_graph(n, wl["edges"], seed=seed, device=device)
+    else:
+        # this rank's row block of a graph over n_global nodes: rows local, columns global
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        row = torch.randint(0, n, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        col = torch.randint(0, n_global, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        loops = torch.arange(n, device=device, dtype=torch.int64)
+        row = torch.cat([row, loops])
+        col = torch.cat([col, loops + rank * n])
+        key = torch.unique(row * n_global + col)
+        row = torch.div(key, n_global, rounding_mode="floor")
+        col = key - row * n_global
+        counts = torch.bincount(row, minlength=n)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        val = (1.0 / counts.to(torch.float32))[row]            # row normalisation: needs no remote degrees
+        A = ops.Csr(rowptr.to(torch.int32), col.to(torch.int32), val.half(), n_global)
+        del key, row, col
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1000)
+    if wl["x_density"] is not None:
+        nnz_x = int(n * f_in * wl["x_density"])
+        xr = torch.randint(0, n, (nnz_x,), generator=g, device=device, dtype=torch.int64)
+        xc = torch.randint(0, f_in, (nnz_x,), generator=g, device=device, dtype=torch.int64)
+        key = torch.unique(xr * f_in + xc)
+        xr = torch.div(key, f_in, rounding_mode="floor")
+        xc = key - xr * f_in
+        xp = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.bincount(xr, minlength=n), 0, out=xp[1:])
+        X = ops.Csr(xp.to(torch.int32), xc.to(torch.int32), torch.ones(key.numel(), device=device).half(), f_in)
+        del key, xr, xc
+    else:
+        X = torch.rand((n, f_in), generator=g, device=device).half()
+    bound = 1.0 / hidden ** 0.5                                   # MOL cell 17 reset_parameters
+    W1t = ((torch.rand((hidden, f_in), generator=g, device=device) * 2 - 1) * bound).half()
+    W2t = ((torch.rand((hidden, hidden), generator=g, device=device) * 2 - 1) * bound).half()
+    return A, X, W1t, W2t
+
+
+def cpu_baseline(torch, ops, A, X, W1t, W2t, frac):
+    """The oracle's plain C loops on this box's host cores, on a bounded row sample of the
+    same workload: rows [0, frac*N) of all four stages, full H tables (baseline only)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    n = A.n_rows
+    rows = max(64, int(n * frac))
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    hidden = W1t.shape[0]
+    # device-side inputs the sample needs, as fp32 on the host
+    if isinstance(X, ops.Csr):
+        W1 = ops.transpose(W1t).float().cpu().numpy()                              # [F_in, hidden]
+        H1 = ops.spmm(X, ops.transpose(W1t), relu=False, use_plan=False).float().cpu().numpy()
+        xe = int(X.rowptr[rows])
+        xrp, xci, xva = (X.rowptr[:rows + 1].cpu().numpy(), X.col[:xe].cpu().numpy(),
+                         X.val[:xe].float().cpu().numpy())
+    else:
+        W1 = np.ascontiguousarray(W1t.float().cpu().numpy().T)
+        H1 = ops.xw_dense(X, W1t).contiguous().float().cpu().numpy()
+        Xs = X[:rows].float().cpu().numpy()
+    D1 = ops.spmm(A, torch.as_tensor(H1, device=W1t.device).half(), relu=True)
+    H2 = ops.xw_dense(D1, W2t).contiguous().float().cpu().numpy()
+    D1s = D1[:rows].float().cpu().numpy()
+    W2 = np.ascontiguousarray(W2t.float().cpu().numpy().T)
+    ae = int(A.rowptr[rows])
+    arp, aci, ava = A.rowptr[:rows + 1].cpu().numpy(), A.col[:ae].cpu().numpy(), A.val[:ae].float().cpu().numpy()
+    out = np.zeros((rows, hidden), np.float32)
+    blocks = [(rows * t // threads, rows * (t + 1) // threads) for t in range(threads)]
+
+    def run(fn):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda b: fn(*b), blocks))
+        return time.perf_counter() - t0
+
+    t = 0.0
+    if isinstance(X, ops.Csr):
+        t += run(lambda lo, hi: O.spmm_f32_into(0, xrp, xci, xva, W1, out, lo, hi, hidden))
+    else:
+        t += run(lambda lo, hi: O.xw_dense_f32_into(Xs, W1, out, lo, hi))
+    t += run(lambda lo, hi: O.spmm_f32_into(1, arp, aci, ava, H1, out, lo, hi, hidden))
+    t += run(lambda lo, hi: O.xw_dense_f32_into(D1s, W2, out, lo, hi))
+    t += run(lambda lo, hi: O.spmm_f32_into(0, arp, aci, ava, H2, out, lo, hi, hidden))
+    return {"value": 2.0 * ae / t, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"rows [0,{rows}) of both layers ({ae} edges per layer), all four stages, full H tables, "
+                      f"fp32, {t:.2f} s of CPU time on {threads} threads"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from sgracex1_amd import dist as sdist
+    from sgracex1_amd import graphs, ops
+    from sgracex1_amd.hipevents import Event
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = WORKLOADS[args.workload]
+    A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device)
+    n, hidden = wl["n"], wl["hidden"]
+    nnz = A.nnz
+    A.plan  # build the row schedules outside the timed region (once per graph)
+    if isinstance(X, ops.Csr):
+        X.plan
+    D1 = torch.empty((n, hidden), dtype=torch.float16, device=device)
+    D2 = torch.empty((n, hidden), dtype=torch.float16, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_ev = 2 * args.steps
+    ev = [(Event(), Event()) for _ in range(n_ev)]
+
+    if world == 1:
+        def step(i, timed):
+            e1 = (ev[2 * i][0].handle, ev[2 * i][1].handle) if timed else None
+            e2 = (ev[2 * i + 1][0].handle, ev[2 * i + 1][1].handle) if timed else None
+            ops.layer_forward(A, X, W1t, relu=True, out=D1, agg_events=e1)
+            ops.layer_forward(A, D1, W2t, relu=False, out=D2, agg_events=e2)
+    else:
+        backend = sdist.hip_backend()
+        bounds = [g * n for g in range(world + 1)]
+        table = torch.empty((n * world, hidden), dtype=torch.float16, device=device)
+
+        def timed_spmm(adj, tab, relu, pair, out):
+            if pair is not None:
+                pair[0].record(stream)
+            ops.spmm(adj, tab, relu=relu, out=out)
+            if pair is not None:
+                pair[1].record(stream)
+            return out
+
+        def step(i, timed):
+            p1 = ev[2 * i] if timed else None
+            p2 = ev[2 * i + 1] if timed else None
+            b1 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p1, D1))
+            b2 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p2, D2))
+            sdist.layer_allgather(b1, A, X, W1t, True, bounds, h_global=table)
+            sdist.layer_allgather(b2, A, D1, W2t, False, bounds, h_global=table)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(0, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([nnz], dtype=torch.int64, device=device)
+        dist.all_reduce(tot)
+        total_nnz = int(tot.item())
+    else:
+        total_nnz = nnz
+
+    # dominant kernel: the A.H aggregation (spmm_sblock_kernel), timed by events the launch path
+    # recorded on its own stream inside the timed region
+    agg_ms = sorted(b.elapsed_ms(e) for b, e in ev)
+    agg_avg_ms = sum(agg_ms) / len(agg_ms)
+    n_cols = A.n_cols
+    es = 2
+    b_alg = nnz * (4 + es + hidden * es) + (n + 1) * 4 + n * hidden * es       # SURVEY 8d, no-reuse gather model
+    b_min = nnz * (4 + es) + (n + 1) * 4 + (n + n_cols) * hidden * es          # compulsory traffic
+    achieved = b_alg / (agg_avg_ms * 1e-3) / 1e9
+    traffic = None
+    if os.path.exists(args.traffic_file):
+        try:
+            tf = json.load(open(args.traffic_file))
+            if tf.get("workload") == args.workload:
+                traffic = tf.get("hbm_bytes_per_launch")
+        except (ValueError, OSError):
+            traffic = None
+
+    ms_per_step = elapsed / args.steps * 1e3
+    line = {
+        "metric": "edges aggregated/sec, 2-layer GCN forward",
+        "value": 2.0 * total_nnz / (elapsed / args.steps),
+        "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 storage, f32 accumulate", "data": "synthetic",
+        "config": {"workload": args.workload, "nodes_per_gpu": n, "edges_per_gpu": nnz, "generator": wl["gen"],
+                   "f_in": wl["f_in"], "hidden": hidden,
+                   "layer1": "gemm_mode=0 sparse X, relu=1" if wl["x_density"] else "gemm_mode=1 dense X, relu=1",
+                   "layer2": "gemm_mode=1 dense X, relu=0",
+                   "exchange": "none" if world == 1 else "RCCL all-gather of H per layer"},
+        "roofline": {"bound": "hbm", "kernel": "spmm_sblock_kernel<f16,8,8> (A.H aggregation)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
+                     "avg_launch_ms": agg_avg_ms, "min_launch_ms": agg_ms[0], "launches_timed": len(agg_ms),
+                     "agg_edges_per_s": nnz / (agg_avg_ms * 1e-3)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,210 @@
+/*
+ * sgx.h -- C ABI of libsgx.so, the MI355X (gfx950) replacement for the one device
+ * kernel of hadimsnj/SGRACEx1: the fused GNN layer  D = act( A . (X . W) ).
+ *
+ * Every entry point below is what the reference's host code binds for this path.
+ * Citations are relative to the reference checkout:
+ *   K.cpp  = gnn-rfsoc-mt-all-2022/src/kernelMatrixmult_all.cpp
+ *   KH     = gnn-rfsoc-mt-all-2022/src/kernelMatrixmult.h
+ *   MM.h   = gnn-rfsoc-mt-all-2022/src/matrix_mult.h
+ *   MOL    = jupyter/molecule_gcn/Graph_Classification.ipynb   (cell numbers, 0-based)
+ *   MMN    = jupyter/test/mmult-master.ipynb
+ *   SG.py  = demo/sgrace_lib/sgrace.py
+ *
+ * Conventions (same as the reference, K.cpp:3762-3774):
+ *   - all matrix pointers are DEVICE pointers (HBM), caller-owned; the library only
+ *     reads inputs and writes D / E / S / the workspace;
+ *   - indices are int32, zero based; CSR = rowPtr[N+1], columnIndex[nnz], values[nnz];
+ *   - B holds the weights TRANSPOSED, [P_w][M_fea] row-major (K.cpp:3043, MOL cell 16);
+ *   - D is [N_adj][P_w] row-major; the feature matrix has M_adj rows (K.cpp:3734);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream and re-entrant per stream; they never synchronise,
+ *     allocate or free, so they can be captured in a hipGraph;
+ *   - return value: SGX_OK (0) or a negative sgx_status.  The reference validates
+ *     nothing and returns nothing (K.cpp:3762); the argument checks are new.
+ */
+#ifndef SGX_H
+#define SGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_VERSION 100
+
+typedef enum sgx_status {
+    SGX_OK = 0,
+    SGX_ERR_NULL = -1,         /* a required pointer is NULL                         */
+    SGX_ERR_SHAPE = -2,        /* a dimension is negative / zero where it may not be */
+    SGX_ERR_UNSUPPORTED = -3,  /* dtype / mode not built                             */
+    SGX_ERR_WORKSPACE = -4,    /* workspace missing or too small                     */
+    SGX_ERR_HIP = -5,          /* a HIP call or launch failed                        */
+    SGX_ERR_CSR = -6,          /* sgx_csr_validate: rowPtr not monotone / index out of range */
+    SGX_ERR_ALIGN = -7         /* pointer or leading dimension not aligned as required */
+} sgx_status;
+
+/* Element type of B, D, values_fea, values_adj (MM.h:76-148 selects ONE type for all:
+ * HALF in the live build, FLOAT optional; SG.py:1545 allocates float32 buffers). */
+typedef enum sgx_dtype { SGX_F16 = 0, SGX_F32 = 1 } sgx_dtype;
+
+/* How sums are formed.
+ *   SGX_ACC_F32       products and sums in fp32, one rounding to the storage type at the
+ *                     end (default; compared with the exact oracle at a stated tolerance).
+ *   SGX_ACC_REF_HALF  fp16 only: every product and every add rounded to binary16, element
+ *                     k of an sblock accumulated in partial-sum lane k mod 4, lanes folded
+ *                     ((p0+p1)+p2)+p3 -- the arithmetic of the reference's HALF build
+ *                     (K.cpp:1829-1884, :2009-2061; MM.h:137-138), bit for bit.       */
+typedef enum sgx_acc_mode { SGX_ACC_F32 = 0, SGX_ACC_REF_HALF = 1 } sgx_acc_mode;
+
+/* ---- row schedule of a CSR matrix ------------------------------------------------
+ * The reference splits rows over ADJ_THREADS / FEA_THREADS by row count and groups
+ * SPMM_BLOCK rows per pipelined loop (K.cpp:3517-3523, :826-845; MM.h:166-191).  On the
+ * GPU the same two decisions are made once per matrix: which rows are packed several to
+ * a wavefront (the sblock path) and which are long enough to be cut into edge chunks
+ * handled by separate wavefronts.  A plan is optional: without one every row takes the
+ * sblock path (correct, slower on power-law graphs). */
+typedef struct sgx_plan sgx_plan;
+
+/* Builds the plan for rowPtr (device).  Synchronises `stream` once (it has to learn how
+ * many long rows there are); not capturable.  n_feat_hint = the P the plan will mostly be
+ * used with (sizes the partial-sum scratch it owns). */
+int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
+                    void *stream);
+void sgx_plan_destroy(sgx_plan *plan);
+/* number of rows that take the split path (for reports / tests) */
+int sgx_plan_long_rows(const sgx_plan *plan);
+
+/* ---- the layer: replaces mmult_top / kernelmult1 (K.cpp:3762, :3969; KH:13-58) ------ */
+typedef struct sgx_layer_desc {
+    /* AXI-Lite scalars of the reference, same names (K.cpp:3777-3790, MMN cell 13) */
+    int32_t gemm_mode;   /* 0: X is CSR (rowPtr_fea, columnIndex_fea, values_fea)
+                            1: X is dense row-major [M_adj][M_fea] in values_fea; rowPtr_fea /
+                               columnIndex_fea ignored (K.cpp:847-865, :985-1012)            */
+    int32_t relu;        /* 1: D = max(D, 0) fused (K.cpp:2586-2590, :801-804)               */
+    int32_t gat_mode;    /* 0: GCN aggregate  A.H ; 1: edge-softmax aggregate (SG.py:649-657) */
+    int32_t N_adj;       /* rows of A and of D                                               */
+    int32_t M_adj;       /* columns of A = rows of X                                         */
+    int32_t M_fea;       /* columns of X = rows of W                                         */
+    int32_t P_w;         /* columns of W and of D; any value >= 1 (no B_WIDTH_BLOCK tail rule) */
+    int32_t bias_count;  /* must be 0; > 0 makes the reference preload and RETURN WITHOUT
+                            COMPUTING (K.cpp:3876-3889) -- reproduced: D is left untouched    */
+    int32_t dtype;       /* sgx_dtype                                                        */
+    int32_t acc_mode;    /* sgx_acc_mode                                                     */
+    int32_t spmm_block;  /* SPMM_BLOCK of the reference (MM.h:188); only observable in
+                            SGX_ACC_REF_HALF (it fixes the partial-sum lane of each element);
+                            0 means 1                                                        */
+    int32_t reserved0;
+
+    /* buffers (device) -- the m_axi ports of K.cpp:3792-3828; the reference's four
+     * aliases per port (rowPtr_fea1..4 etc., main_float.cpp:880-887) collapse to one */
+    const void    *B;                 /* W^T  [P_w][M_fea]                          */
+    void          *D;                 /* out  [N_adj][P_w]                          */
+    const int32_t *rowPtr_fea;        /* [M_adj+1]            (gemm_mode 0)          */
+    const int32_t *columnIndex_fea;   /* [nnz_fea]            (gemm_mode 0)          */
+    const void    *values_fea;        /* [nnz_fea] or dense [M_adj*M_fea]            */
+    const int32_t *rowPtr_adj;        /* [N_adj+1]                                   */
+    const int32_t *columnIndex_adj;   /* [nnz_adj]                                   */
+    const void    *values_adj;        /* [nnz_adj]                                   */
+
+    /* GAT (gat_mode = 1): single head as in the reference (SG.py:1176-1178) */
+    const void    *attention;         /* a [2*P_w]  (a1 = a[:P_w], a2 = a[P_w:]), same dtype */
+    void          *E;                 /* optional out [nnz_adj] fp32: LeakyReLU(e_ij)        */
+    void          *S;                 /* optional out [nnz_adj] fp32: softmax alpha_ij       */
+    float          alpha;             /* LeakyReLU slope (SG.py:1172, default 0.2)           */
+    int32_t        reserved1;
+
+    /* scratch in HBM for H = X.W (the reference's on-chip C tile, K.cpp:27) and split-row
+     * partial sums; at least sgx_layer_workspace_bytes(desc) bytes, 256-byte aligned */
+    void          *workspace;
+    size_t         workspace_bytes;
+
+    /* optional row schedules (see sgx_plan); NULL = none */
+    const sgx_plan *plan_adj;
+    const sgx_plan *plan_fea;
+
+    /* optional profiling taps, the counterpart of the reference's profiling[] port
+     * (K.cpp:3948-3962): hipEvent_t handles (as void*) recorded on `stream` right before and
+     * right after the aggregation stage (A.H or GAT).  NULL = not recorded. */
+    void *ev_agg_begin;
+    void *ev_agg_end;
+} sgx_layer_desc;
+
+size_t sgx_layer_workspace_bytes(const sgx_layer_desc *desc);
+int    sgx_layer_forward(const sgx_layer_desc *desc, void *stream);
+
+/* ---- the stages, individually (the dataflow processes of K.cpp:3629-3752) ---------- */
+
+/* A.H aggregation = loop_adj / compute2 / writec (K.cpp:3339, :2483, :713):
+ *   D[r][0:n_feat] = act( sum_e values[e] * H[columnIndex[e]][0:n_feat] ),  r in [0,n_rows)
+ * H is [n_cols][ldh], D is [n_rows][ldd] (leading dimensions in elements).  For the 16-byte
+ * gather path H must be 16-byte aligned with ldh*sizeof(elem) a multiple of 16; otherwise a
+ * scalar path is taken.  scratch/scratch_bytes: needed only when `plan` has long rows
+ * (sgx_spmm_scratch_bytes). */
+int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu,
+                 int n_rows, int n_cols, int n_feat,
+                 const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                 const void *H, int64_t ldh, void *D, int64_t ldd,
+                 const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream);
+size_t sgx_spmm_scratch_bytes(const sgx_plan *plan, int n_feat);
+
+/* X.W with dense X = loop_fea / compute1 in gemm_mode 1 (K.cpp:2932, :2605, :847-865),
+ * on the matrix cores:  H[r][0:P] = sum_k X[r][k] * Wt[p][k].
+ * X [n_rows][ldx], Wt [P][ldw] (= B), H [n_rows][ldh]; columns P..ldh-1 of H are zeroed. */
+int sgx_xw_dense(int dtype, int acc_mode, int n_rows, int M_fea, int P,
+                 const void *X, int64_t ldx, const void *Wt, int64_t ldw,
+                 void *H, int64_t ldh, void *stream);
+
+/* X.W with CSR X = loop_fea / compute1 in gemm_mode 0 (K.cpp:1960-2078).
+ * W_rowmajor is [M_fea][ldw] (use sgx_transpose to get it from B). */
+int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P,
+                  const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                  const void *W_rowmajor, int64_t ldw, void *H, int64_t ldh,
+                  const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream);
+
+/* out[c][r] = in[r][c]; in [rows][ldi], out [cols][ldo]; pads out columns rows..ldo-1 with 0.
+ * The weight-tile load B_accel[i][j] = B[i + j*M_fea] (K.cpp:3038-3051). */
+int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
+                  void *out, int64_t ldo, void *stream);
+
+/* GAT aggregation on an already computed Wh (SG.py:309-314, :634-661), single head:
+ *   e_ij = LeakyReLU_alpha(Wh_i.a1 + Wh_j.a2) for stored edges with values[e] > 0,
+ *   alpha_ij = softmax_j(e_ij),  D_i = act(sum_j alpha_ij Wh_j).
+ * s_scratch: 2*n_rows floats (the per-node scores Wh.a1, Wh.a2).  E/S optional [nnz] fp32. */
+int sgx_gat_aggregate(int dtype, int relu, int n_rows, int n_feat, float alpha,
+                      const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                      const void *Wh, int64_t ldh, const void *attention,
+                      void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream);
+
+/* ---- helpers on either side of the path (SURVEY 8f "next" rows) -------------------- */
+
+/* Checks rowPtr[0]==0, monotone, rowPtr[n_rows]==nnz and 0 <= columnIndex < n_cols on the
+ * device.  Synchronises the stream.  Returns SGX_OK or SGX_ERR_CSR. */
+int sgx_csr_validate(const int32_t *rowPtr, const int32_t *columnIndex, int n_rows, int n_cols,
+                     int64_t nnz, void *stream);
+
+/* COO (row index per edge, sorted by row) -> CSR row pointer; the GAT bitstream is fed COO
+ * (SG.py:1222, :1245).  rowPtr [n_rows+1]. */
+int sgx_coo_to_csr(const int32_t *rowIndex, int64_t nnz, int n_rows, int32_t *rowPtr, void *stream);
+
+/* ReLU backward of RPYNQ (MOL cell 16): grad[i] = (out[i] == 0) ? 0 : grad[i], in place. */
+int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
+                           void *stream);
+
+/* hipEvent_t helpers for the profiling taps of sgx_layer_desc (handles travel as void*), so that
+ * a host that does not link the HIP runtime itself can time launches on the library's runtime.
+ * sgx_event_elapsed_ms waits for `end` and returns the milliseconds between the two events. */
+int sgx_event_create(void **event);
+int sgx_event_destroy(void *event);
+int sgx_event_record(void *event, void *stream);
+int sgx_event_elapsed_ms(void *begin, void *end, float *ms);
+
+int         sgx_version(void);
+const char *sgx_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGX_H */

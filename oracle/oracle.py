@@ -107,6 +107,22 @@ def spmm_f32(relu, adj, H, P=None, rows=None):
     return D
 
 
+def spmm_f32_into(relu, rowptr, col, val, H, D, row_begin, row_end, P):
+    """In-place row-range form of spmm_f32 (no copies; callable from several threads)."""
+    rc = lib().orc_spmm_f32(relu, ctypes.c_int64(row_begin), ctypes.c_int64(row_end), P,
+                            ctypes.c_int64(H.shape[1]), ctypes.c_int64(D.shape[1]),
+                            _p(rowptr), _p(col), _p(val), _p(H), _p(D))
+    assert rc == 0, rc
+
+
+def xw_dense_f32_into(X, W, H, row_begin, row_end):
+    """H[rows] = X[rows] @ W, W row-major [M, P]; in place, thread-safe over disjoint rows."""
+    M, P = W.shape
+    rc = lib().orc_xw_dense_f32(ctypes.c_int64(row_begin), ctypes.c_int64(row_end), M, P,
+                                ctypes.c_int64(X.shape[1]), ctypes.c_int64(H.shape[1]), _p(X), _p(W), _p(H))
+    assert rc == 0, rc
+
+
 def layer_refhalf(gemm_mode, relu, adj, fea, Wt, N=None, M_adj=None, spmm_block=1, lat_fea=4,
                   lat_adj=4, fea_threads=1, adj_threads=1, return_h=False):
     """Bit-accurate model of the reference HALF build; returns float16 arrays."""

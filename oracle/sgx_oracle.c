@@ -192,6 +192,28 @@ int orc_spmm_f32(int relu, int64_t row_begin, int64_t row_end, int P, int64_t ld
     return 0;
 }
 
+/* Dense X.W for rows [row_begin,row_end): H[r][j] = sum_k X[r][k] * W[k][j], W row-major
+ * [M][P] -- the `support = torch.mm(input, weight)` half of the reference's CPU path
+ * (GNN_arc.pdf Listing 1.3; MOL cell 17 acc==0 branch).  CPU-baseline kernel.          */
+int orc_xw_dense_f32(int64_t row_begin, int64_t row_end, int M, int P, int64_t ldx, int64_t ldh,
+                     const float *X, const float *W, float *H)
+{
+    float acc[1024];
+    if (P > 1024) return -2;
+    for (int64_t r = row_begin; r < row_end; r++) {
+        for (int j = 0; j < P; j++) acc[j] = 0.0f;
+        const float *x = X + (size_t)r * ldx;
+        for (int k = 0; k < M; k++) {
+            float xv = x[k];
+            const float *w = W + (size_t)k * P;
+            for (int j = 0; j < P; j++) acc[j] += xv * w[j];
+        }
+        float *h = H + (size_t)r * ldh;
+        for (int j = 0; j < P; j++) h[j] = acc[j];
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Reference-half model (bit-accurate restatement of the HALF build).          */
 /* ------------------------------------------------------------------------- */

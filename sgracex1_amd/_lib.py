@@ -1,0 +1,117 @@
+"""ctypes binding of libsgx.so (the C ABI declared in include/sgx.h).
+
+The library is the only backend.  If it is missing or does not load, importing this module
+raises -- there is no CPU or PyTorch fallback for the accelerated path.
+"""
+import ctypes
+import os
+
+# PyTorch-ROCm ships its own HIP runtime; importing it first makes that copy the one this process
+# (and libsgx.so, whose libamdhip64 dependency then resolves to it) uses -- two runtimes in one
+# process cannot share streams or allocations.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgx.so")
+
+SGX_F16, SGX_F32 = 0, 1
+SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
+
+# every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
+SYMBOLS = [
+    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows",
+    "sgx_layer_workspace_bytes", "sgx_layer_forward",
+    "sgx_spmm_csr", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
+    "sgx_gat_aggregate", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
+    "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
+    "sgx_version", "sgx_status_string",
+]
+
+
+class SgxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        super().__init__(f"{where}: {status_string(status)} (sgx_status {status})")
+
+
+class LayerDesc(ctypes.Structure):
+    """struct sgx_layer_desc -- field order and types must match include/sgx.h."""
+    _fields_ = [
+        ("gemm_mode", ctypes.c_int32), ("relu", ctypes.c_int32), ("gat_mode", ctypes.c_int32),
+        ("N_adj", ctypes.c_int32), ("M_adj", ctypes.c_int32), ("M_fea", ctypes.c_int32),
+        ("P_w", ctypes.c_int32), ("bias_count", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("acc_mode", ctypes.c_int32), ("spmm_block", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("B", ctypes.c_void_p), ("D", ctypes.c_void_p),
+        ("rowPtr_fea", ctypes.c_void_p), ("columnIndex_fea", ctypes.c_void_p), ("values_fea", ctypes.c_void_p),
+        ("rowPtr_adj", ctypes.c_void_p), ("columnIndex_adj", ctypes.c_void_p), ("values_adj", ctypes.c_void_p),
+        ("attention", ctypes.c_void_p), ("E", ctypes.c_void_p), ("S", ctypes.c_void_p),
+        ("alpha", ctypes.c_float), ("reserved1", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("plan_adj", ctypes.c_void_p), ("plan_fea", ctypes.c_void_p),
+        ("ev_agg_begin", ctypes.c_void_p), ("ev_agg_end", ctypes.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first (python -m sgracex1_amd.build); "
+            "sgracex1_amd has no other backend")
+    lib = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    lib.sgx_plan_create.argtypes = [ctypes.POINTER(vp), vp, c_int, c_int, vp]
+    lib.sgx_plan_create.restype = c_int
+    lib.sgx_plan_destroy.argtypes = [vp]
+    lib.sgx_plan_destroy.restype = None
+    lib.sgx_plan_long_rows.argtypes = [vp]
+    lib.sgx_plan_long_rows.restype = c_int
+    lib.sgx_layer_workspace_bytes.argtypes = [ctypes.POINTER(LayerDesc)]
+    lib.sgx_layer_workspace_bytes.restype = sz
+    lib.sgx_layer_forward.argtypes = [ctypes.POINTER(LayerDesc), vp]
+    lib.sgx_layer_forward.restype = c_int
+    lib.sgx_spmm_csr.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_i64, vp, c_i64,
+                                 vp, vp, sz, vp]
+    lib.sgx_spmm_csr.restype = c_int
+    lib.sgx_spmm_scratch_bytes.argtypes = [vp, c_int]
+    lib.sgx_spmm_scratch_bytes.restype = sz
+    lib.sgx_xw_dense.argtypes = [c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp]
+    lib.sgx_xw_dense.restype = c_int
+    lib.sgx_xw_sparse.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_i64, vp, c_i64,
+                                  vp, vp, sz, vp]
+    lib.sgx_xw_sparse.restype = c_int
+    lib.sgx_transpose.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp]
+    lib.sgx_transpose.restype = c_int
+    lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
+                                      vp, c_i64, vp, vp, vp, vp]
+    lib.sgx_gat_aggregate.restype = c_int
+    lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]
+    lib.sgx_csr_validate.restype = c_int
+    lib.sgx_coo_to_csr.argtypes = [vp, c_i64, c_int, vp, vp]
+    lib.sgx_coo_to_csr.restype = c_int
+    lib.sgx_relu_mask_backward.argtypes = [c_int, vp, c_int, vp, c_i64, vp]
+    lib.sgx_relu_mask_backward.restype = c_int
+    lib.sgx_event_create.argtypes = [ctypes.POINTER(vp)]
+    lib.sgx_event_create.restype = c_int
+    lib.sgx_event_destroy.argtypes = [vp]
+    lib.sgx_event_destroy.restype = c_int
+    lib.sgx_event_record.argtypes = [vp, vp]
+    lib.sgx_event_record.restype = c_int
+    lib.sgx_event_elapsed_ms.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.sgx_event_elapsed_ms.restype = c_int
+    lib.sgx_version.argtypes = []
+    lib.sgx_version.restype = c_int
+    lib.sgx_status_string.argtypes = [c_int]
+    lib.sgx_status_string.restype = ctypes.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def status_string(status):
+    return lib.sgx_status_string(int(status)).decode()
+
+
+def check(status, where):
+    if status != 0:
+        raise SgxError(status, where)

@@ -1,0 +1,229 @@
+// Single-head GAT aggregation for gfx950 (the GAT bitstream has no public HLS source; the
+// arithmetic is the reference's CPU emulation, SG.py:309-314 and :634-661):
+//     s1_i = Wh_i . a[:F]      s2_j = Wh_j . a[F:]
+//     e_ij = LeakyReLU_alpha(s1_i + s2_j)            for stored edges with values[e] > 0
+//     alpha_ij = softmax_j(e_ij)                     (rows of the masked dense matrix)
+//     D_i = act( sum_j alpha_ij Wh_j )
+// The emulation builds dense N x N matrices; here the softmax runs over the CSR row: one group
+// of LPR lanes per row (the same sblock layout as spmm_csr.hip), pass 1 = online max / sum over
+// the 4-byte scores, pass 2 = the 16-byte row gathers weighted by alpha_ij.  The hardware's
+// per-edge side outputs E (pre-softmax) and S (softmax) (SG.py:500-502) are optional.
+// Rows with no positive edge produce 0 (never reached from the reference's call path: sym_norm2
+// adds self loops, SG.py:42).
+#include "sgx_device.h"
+
+#include <math.h>
+
+namespace {
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_scores_kernel(int n_rows, int n_feat, const T *__restrict__ Wh, int64_t ldh,
+                                                           const T *__restrict__ att, float *__restrict__ s1,
+                                                           float *__restrict__ s2, int vec_ok)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int TILE = LPR * VEC;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int64_t r = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;
+    float p1 = 0.0f, p2 = 0.0f;
+    if (r < n_rows) {
+        for (int c0 = sub * VEC; c0 < n_feat; c0 += TILE) {
+            T h[VEC];
+            if (VEC > 1 && vec_ok && c0 + VEC <= n_feat) {
+                *reinterpret_cast<u32x4 *>(h) = *reinterpret_cast<const u32x4 *>(Wh + r * ldh + c0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) h[i] = (c0 + i < n_feat) ? Wh[r * ldh + c0 + i] : (T)0;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                if (c0 + i < n_feat) {
+                    p1 = __builtin_fmaf(Elem<T>::to_f32(h[i]), Elem<T>::to_f32(att[c0 + i]), p1);
+                    p2 = __builtin_fmaf(Elem<T>::to_f32(h[i]), Elem<T>::to_f32(att[n_feat + c0 + i]), p2);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) {
+        p1 += __shfl_xor(p1, off);
+        p2 += __shfl_xor(p2, off);
+    }
+    if (r < n_rows && sub == 0) { s1[r] = p1; s2[r] = p2; }
+}
+
+__device__ __forceinline__ float leaky(float x, float alpha) { return x > 0.0f ? x : x * alpha; }
+
+// merge two online-softmax states (m, l); (-inf, 0) is the empty state
+__device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, float l2)
+{
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { m = mn; l = 0.0f; return; }
+    l = l * expf(m - mn) + l2 * expf(m2 - mn);
+    m = mn;
+}
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
+    int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
+    const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
+    T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int TILE = LPR * VEC;
+    constexpr int UNR = LPR < 8 ? LPR : 8;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int64_t r = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
+    const bool live = r < n_rows;
+    int e0 = 0, e1 = 0;
+    float si = 0.0f;
+    if (live) { e0 = rowptr[r]; e1 = rowptr[r + 1]; si = s1[r]; }
+
+    // pass 1: running max and sum of exp over the row's positive edges
+    float m = -INFINITY, l = 0.0f;
+    for (int idx = e0 + sub; idx < e1; idx += LPR) {
+        if (Elem<T>::to_f32(val[idx]) > 0.0f) {
+            const float x = leaky(si + s2[col[idx]], alpha);
+            softmax_merge(m, l, x, 1.0f);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        softmax_merge(m, l, m2, l2);
+    }
+    const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+
+    // pass 2: weighted gather of the neighbour rows
+    for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+        const int col0 = c0 + sub * VEC;
+        const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        for (int base = e0; base < e1; base += LPR) {
+            const int idx = base + sub;
+            int c = 0;
+            float p = 0.0f;
+            if (idx < e1) {
+                c = col[idx];
+                const float x = leaky(si + s2[c], alpha);
+                if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(x - m) * inv_l;
+                if (c0 == 0) {
+                    if (E) E[idx] = x;
+                    if (S) S[idx] = p;
+                }
+            }
+            const int n = e1 - base;
+#pragma unroll 1
+            for (int t0 = 0; t0 < LPR; t0 += UNR) {
+                if (t0 >= n) break;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int t = t0 + u;
+                    const int cc = __shfl(c, t, LPR);
+                    const float pp = __shfl(p, t, LPR);
+                    const unsigned off = (t < n && col_off != kOOB) ? (unsigned)cc * ld_bytes + col_off : kOOB;
+                    Gather<T, VEC>::run(acc, pp, rsrc, off);
+                }
+            }
+        }
+        if (live && col0 < n_feat) {
+            T out[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                T v = Elem<T>::from_f32(acc[i]);
+                out[i] = (!relu || v > (T)0) ? v : (T)0;           // SG.py:660-661
+            }
+            T *drow = D + r * ldd;
+            if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
+                *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (col0 + i < n_feat) drow[col0 + i] = out[i];
+            }
+        }
+    }
+}
+
+struct GatArgs {
+    int relu, n_rows, n_feat;
+    float alpha;
+    const int32_t *rowptr, *col;
+    const void *val, *Wh, *att;
+    int64_t ldh, ldd;
+    unsigned h_bytes, ld_bytes;
+    void *D;
+    float *E, *S, *s;
+    int vec_ok, vec_store;
+    hipStream_t stream;
+};
+
+template <typename T, int VEC, int LPR>
+int gat_launch_one(const GatArgs &a)
+{
+    const int rows_per_block = (64 / LPR) * (kBlock / 64);
+    const unsigned grid = (unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block);
+    float *s1 = a.s, *s2 = a.s + a.n_rows;
+    hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_feat,
+                       (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2, a.vec_ok);
+    SGX_LAUNCH_CHECK();
+    hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_feat,
+                       a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
+                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+template <typename T, int VEC>
+int gat_launch_lpr(const GatArgs &a, int lpr)
+{
+    switch (lpr) {
+    case 1: return gat_launch_one<T, VEC, 1>(a);
+    case 2: return gat_launch_one<T, VEC, 2>(a);
+    case 4: return gat_launch_one<T, VEC, 4>(a);
+    case 8: return gat_launch_one<T, VEC, 8>(a);
+    case 16: return gat_launch_one<T, VEC, 16>(a);
+    case 32: return gat_launch_one<T, VEC, 32>(a);
+    default: return gat_launch_one<T, VEC, 64>(a);
+    }
+}
+
+}  // namespace
+
+extern "C" int sgx_gat_aggregate(int dtype, int relu, int n_rows, int n_feat, float alpha,
+                                 const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                                 const void *Wh, int64_t ldh, const void *attention,
+                                 void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream)
+{
+    if (n_rows < 0 || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
+    if (n_rows == 0) return SGX_OK;
+    if (!rowPtr || !columnIndex || !values || !Wh || !attention || !D) return SGX_ERR_NULL;
+    if (!s_scratch) return SGX_ERR_WORKSPACE;
+    if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    const size_t es = sgx_elem_size(dtype);
+    const unsigned long long table_bytes = (unsigned long long)n_rows * (unsigned long long)ldh * es;
+    if (table_bytes >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
+    GatArgs a;
+    a.relu = relu; a.n_rows = n_rows; a.n_feat = n_feat; a.alpha = alpha;
+    a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
+    a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
+    a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
+    a.vec_ok = ((uintptr_t)Wh % 16 == 0) && ((ldh * es) % 16 == 0);
+    a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
+    const int per16 = (int)(16 / es);
+    if (a.vec_ok) {
+        int lpr = sgx_next_pow2((n_feat + per16 - 1) / per16);
+        if (lpr > 64) lpr = 64;
+        return dtype == SGX_F16 ? gat_launch_lpr<f16, 8>(a, lpr) : gat_launch_lpr<float, 4>(a, lpr);
+    }
+    int lpr = sgx_next_pow2(n_feat);
+    if (lpr > 64) lpr = 64;
+    return dtype == SGX_F16 ? gat_launch_lpr<f16, 1>(a, lpr) : gat_launch_lpr<float, 1>(a, lpr);
+}

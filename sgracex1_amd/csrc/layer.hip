@@ -1,0 +1,159 @@
+// sgx_layer_forward: the drop-in for mmult_top / kernelmult1 (K.cpp:3762, :3969).
+//
+// The reference overlaps X.W of output tile b+1 with A.H of tile b through a ping-pong PIPO
+// (mmult_wrapper, K.cpp:3629-3752) and re-streams both CSR matrices once per B_WIDTH_BLOCK
+// columns.  Here all P_w columns of a row are produced at once, so each CSR is read exactly
+// once and the two stages are two launches on one stream with H = X.W kept in HBM scratch
+// (in the storage dtype, as the reference keeps its C tile in `half`).
+#include "sgx_internal.h"
+
+namespace {
+
+struct Carve {
+    size_t h_off, h_bytes;        // H  [M_adj][ldh]
+    size_t w_off, w_bytes;        // W  [M_fea][ldh]  (row-major copy of B, gemm_mode 0 only)
+    size_t s_off, s_bytes;        // split-row partial sums (max of both stages)
+    size_t g_off, g_bytes;        // GAT per-node scores, 2*N floats
+    size_t total;
+};
+
+Carve carve(const sgx_layer_desc *d)
+{
+    Carve c;
+    const size_t es = sgx_elem_size(d->dtype);
+    const size_t ldh = (size_t)sgx_ldh(d->dtype, d->P_w);
+    size_t off = 0;
+    c.h_off = off; c.h_bytes = sgx_align_up((size_t)d->M_adj * ldh * es, 256); off += c.h_bytes;
+    c.w_off = off; c.w_bytes = d->gemm_mode == 0 ? sgx_align_up((size_t)d->M_fea * ldh * es, 256) : 0; off += c.w_bytes;
+    size_t s1 = sgx_spmm_scratch_bytes(d->plan_adj, d->P_w);
+    size_t s2 = d->gemm_mode == 0 ? sgx_spmm_scratch_bytes(d->plan_fea, d->P_w) : 0;
+    c.s_off = off; c.s_bytes = s1 > s2 ? s1 : s2; off += c.s_bytes;
+    c.g_off = off; c.g_bytes = d->gat_mode ? sgx_align_up((size_t)d->N_adj * 2 * sizeof(float), 256) : 0; off += c.g_bytes;
+    c.total = off;
+    return c;
+}
+
+int check_desc(const sgx_layer_desc *d)
+{
+    if (!d) return SGX_ERR_NULL;
+    if (d->N_adj < 0 || d->M_adj < 0 || d->M_fea < 1 || d->P_w < 1) return SGX_ERR_SHAPE;
+    if (d->dtype != SGX_F16 && d->dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    if (d->gemm_mode != 0 && d->gemm_mode != 1) return SGX_ERR_UNSUPPORTED;   // 2 = backward offload, not in the public HLS
+    return SGX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sgx_layer_workspace_bytes(const sgx_layer_desc *desc)
+{
+    if (check_desc(desc) != SGX_OK) return 0;
+    return carve(desc).total;
+}
+
+extern "C" int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P,
+                             const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                             const void *W_rowmajor, int64_t ldw, void *H, int64_t ldh,
+                             const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
+{
+    // C[r][:] = sum_k Xval[k] * W[Xcol[k]][:]  (K.cpp:2009-2061): the aggregation kernel with the
+    // weight matrix as the gathered table (it fits L2: M_fea x P elements)
+    return sgx_spmm_launch(dtype, acc_mode, spmm_block, /*relu*/0, n_rows, M_fea, P, rowPtr, columnIndex, values,
+                           W_rowmajor, ldw, H, ldh, plan, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
+{
+    int rc = check_desc(d);
+    if (rc != SGX_OK) return rc;
+    // K.cpp:3876-3889: with bias_count > 0 the kernel only preloads bias/shift/multiplier and returns
+    if (d->bias_count > 0) return SGX_OK;
+    if (d->N_adj == 0) return SGX_OK;
+    if (!d->B || !d->D || !d->rowPtr_adj || !d->values_fea) return SGX_ERR_NULL;
+    if (d->gemm_mode == 0 && (!d->rowPtr_fea)) return SGX_ERR_NULL;
+    const Carve c = carve(d);
+    if (!d->workspace || d->workspace_bytes < c.total) return SGX_ERR_WORKSPACE;
+    if ((uintptr_t)d->workspace % 256 != 0) return SGX_ERR_ALIGN;
+
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)d->workspace;
+    void *H = ws + c.h_off;
+    void *W = ws + c.w_off;
+    void *scratch = c.s_bytes ? ws + c.s_off : nullptr;
+    const int64_t ldh = sgx_ldh(d->dtype, d->P_w);
+
+    // stage 1: H = X . W          (loop_fea, K.cpp:2932)
+    if (d->gemm_mode == 0) {
+        rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, d->B, d->M_fea, W, ldh, s);      // B [P][M] -> W [M][ldh]
+        if (rc != SGX_OK) return rc;
+        rc = sgx_xw_sparse(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
+                           d->columnIndex_fea, d->values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s);
+    } else {
+        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->M_adj, d->M_fea, d->P_w, d->values_fea, d->M_fea, d->B, d->M_fea,
+                          H, ldh, s);
+    }
+    if (rc != SGX_OK) return rc;
+
+    // stage 2: D = act(A . H)     (loop_adj, K.cpp:3339) or the edge-softmax aggregate (SG.py:634-661)
+    if (d->ev_agg_begin) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_begin, s));
+    if (d->gat_mode) {
+        if (!d->attention) return SGX_ERR_NULL;
+        rc = sgx_gat_aggregate(d->dtype, d->relu, d->N_adj, d->P_w, d->alpha, d->rowPtr_adj, d->columnIndex_adj,
+                               d->values_adj, H, ldh, d->attention, d->D, d->P_w, (float *)d->E, (float *)d->S,
+                               (float *)(ws + c.g_off), s);
+    } else {
+        rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,
+                             d->rowPtr_adj, d->columnIndex_adj, d->values_adj, H, ldh, d->D, d->P_w, d->plan_adj,
+                             scratch, c.s_bytes, s);
+    }
+    if (rc != SGX_OK) return rc;
+    if (d->ev_agg_end) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_end, s));
+    return SGX_OK;
+}
+
+extern "C" int sgx_event_create(void **event)
+{
+    if (!event) return SGX_ERR_NULL;
+    hipEvent_t e;
+    SGX_HIP_CHECK(hipEventCreate(&e));
+    *event = (void *)e;
+    return SGX_OK;
+}
+
+extern "C" int sgx_event_destroy(void *event)
+{
+    if (!event) return SGX_OK;
+    SGX_HIP_CHECK(hipEventDestroy((hipEvent_t)event));
+    return SGX_OK;
+}
+
+extern "C" int sgx_event_record(void *event, void *stream)
+{
+    if (!event) return SGX_ERR_NULL;
+    SGX_HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return SGX_OK;
+}
+
+extern "C" int sgx_event_elapsed_ms(void *begin, void *end, float *ms)
+{
+    if (!begin || !end || !ms) return SGX_ERR_NULL;
+    SGX_HIP_CHECK(hipEventSynchronize((hipEvent_t)end));
+    SGX_HIP_CHECK(hipEventElapsedTime(ms, (hipEvent_t)begin, (hipEvent_t)end));
+    return SGX_OK;
+}
+
+extern "C" int sgx_version(void) { return SGX_VERSION; }
+
+extern "C" const char *sgx_status_string(int status)
+{
+    switch (status) {
+    case SGX_OK: return "ok";
+    case SGX_ERR_NULL: return "required pointer is NULL";
+    case SGX_ERR_SHAPE: return "bad dimension";
+    case SGX_ERR_UNSUPPORTED: return "dtype or mode not supported";
+    case SGX_ERR_WORKSPACE: return "workspace missing or too small";
+    case SGX_ERR_HIP: return "HIP call or kernel launch failed";
+    case SGX_ERR_CSR: return "CSR structure invalid";
+    case SGX_ERR_ALIGN: return "pointer or leading dimension misaligned";
+    default: return "unknown status";
+    }
+}

@@ -1,0 +1,64 @@
+// Device-side helpers shared by the aggregation kernels (spmm_csr.hip, gat.hip).
+#pragma once
+#include "sgx_internal.h"
+
+constexpr int kBlock = 256;              // 4 wavefronts
+constexpr unsigned kOOB = 0xFFFFFFF0u;   // buffer offset that is out of range for any table
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+
+template <typename T> struct Elem;
+template <> struct Elem<f16> {
+    static constexpr int kVec = 8;       // elements per 16-byte gather
+    static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
+    static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }   // v_cvt_f16_f32: RNE
+};
+template <> struct Elem<float> {
+    static constexpr int kVec = 4;
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+
+// acc[0:VEC] += a * (VEC elements of type T held in `raw`)
+template <typename T, int VEC> struct Fma;
+template <> struct Fma<f16, 8> {
+    static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
+        union { u32x4 v; f16 h[8]; } u; u.v = raw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(a, (float)u.h[i], acc[i]);
+    }
+};
+template <> struct Fma<float, 4> {
+    static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
+        union { u32x4 v; float f[4]; } u; u.v = raw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(a, u.f[i], acc[i]);
+    }
+};
+
+// One gather of VEC elements at byte offset `off` of the table behind `rsrc`.
+template <typename T, int VEC> struct Gather;
+template <> struct Gather<f16, 8> {
+    static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        Fma<f16, 8>::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+};
+template <> struct Gather<float, 4> {
+    static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        Fma<float, 4>::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+};
+template <> struct Gather<f16, 1> {
+    static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        unsigned short raw = __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+        union { unsigned short s; f16 h; } u; u.s = raw;
+        acc[0] = __builtin_fmaf(a, (float)u.h, acc[0]);
+    }
+};
+template <> struct Gather<float, 1> {
+    static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        acc[0] = __builtin_fmaf(a, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)), acc[0]);
+    }
+};
+

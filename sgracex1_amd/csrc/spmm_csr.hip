@@ -1,0 +1,296 @@
+// CSR aggregation  D = act(A . H)  for gfx950 -- the A.H stage of the reference
+// (loop_adj / compute2 / dsp_kernel_wrapper_adj / writec: K.cpp:3339, :2483, :1778, :713)
+// and, with H := W, the sparse-feature X.W stage (compute1 in gemm_mode 0, K.cpp:1960-2078).
+//
+// Mapping to the hardware (HBM-bound: ~2*F flops per 6+2F bytes):
+//   * sblock path.  A wavefront is cut into groups of LPR lanes; LPR lanes x 16 bytes cover
+//     one row of H (F=64 fp16 -> 8 lanes, one 128-byte line).  Each group owns ONE row of A,
+//     so a wavefront works on 64/LPR rows at once -- the reference's SPMM_BLOCK row grouping
+//     (K.cpp:826-845) with the running-nnz interval test replaced by lane ownership.  Per
+//     step a group reads LPR (column, value) pairs with one coalesced load each, broadcasts
+//     them with lane shuffles, and issues LPR independent 16-byte gathers (buffer loads: an
+//     edge past the end of the row gets an out-of-range offset, which returns 0 without
+//     touching memory), i.e. 64 gathers of 16 bytes in flight per wavefront.
+//   * split path.  Rows longer than plan->long_threshold are cut into chunks; one wavefront
+//     sums one chunk with all 64/LPR groups on the same row, the groups are folded with
+//     lane shuffles, the fp32 partial rows are added in chunk order by a small second kernel.
+//   * products and sums in fp32, one rounding to the storage type; ReLU fused into the store.
+#include "sgx_device.h"
+
+namespace {
+
+// Sum of  values[e] * H[columnIndex[e]][col0 : col0+VEC]  over e in [e0, e1) stepping `stride`
+// edges between this group's LPR-edge pieces.  `col_off` = byte offset of this lane's columns
+// inside a row of H, or kOOB when the lane has no valid column.
+template <typename T, int VEC, int LPR>
+__device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int stride, int sub,
+                                                 const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                 __amdgpu_buffer_rsrc_t rsrc, unsigned ld_bytes, unsigned col_off)
+{
+    int c_next = 0;
+    T a_next = (T)0;
+    if (e0 + sub < e1) {
+        c_next = __builtin_nontemporal_load(col + e0 + sub);    // streamed once: keep L2 for H
+        a_next = __builtin_nontemporal_load(val + e0 + sub);
+    }
+    for (int base = e0; base < e1; base += stride) {
+        const int c = c_next;
+        const float a = Elem<T>::to_f32(a_next);
+        // the next piece's (column, value) pair is requested before this piece's gathers
+        const int nidx = base + stride + sub;
+        c_next = 0;
+        a_next = (T)0;
+        if (nidx < e1) {
+            c_next = __builtin_nontemporal_load(col + nidx);
+            a_next = __builtin_nontemporal_load(val + nidx);
+        }
+        const int n = e1 - base;                                // valid edges in this piece (>= 1)
+        constexpr int UNR = LPR < 8 ? LPR : 8;                  // gathers kept in flight per lane
+#pragma unroll 1
+        for (int t0 = 0; t0 < LPR; t0 += UNR) {
+            if (t0 >= n) break;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int t = t0 + u;
+                const int cc = __shfl(c, t, LPR);
+                const float aa = __shfl(a, t, LPR);
+                const unsigned off = (t < n && col_off != kOOB) ? (unsigned)cc * ld_bytes + col_off : kOOB;
+                Gather<T, VEC>::run(acc, aa, rsrc, off);
+            }
+        }
+    }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_feat, const float *acc, int relu,
+                                          bool vec_store)
+{
+    T out[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        T v = Elem<T>::from_f32(acc[i]);
+        // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
+        out[i] = (!relu || v > (T)0) ? v : (T)0;
+    }
+    if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
+        *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            if (col0 + i < n_feat) drow[col0 + i] = out[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sblock path: one group of LPR lanes per row, 64/LPR rows per wavefront.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
+    int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
+    T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store)
+{
+    constexpr int RPW = 64 / LPR;                 // rows per wavefront
+    constexpr int TILE = LPR * VEC;               // columns covered per pass
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
+
+    for (int64_t r0 = wave * RPW; r0 < n_rows; r0 += n_waves * RPW) {
+        const int64_t r = r0 + grp;
+        int e0 = 0, e1 = 0;
+        bool live = r < n_rows;
+        if (live) {
+            e0 = rowptr[r];
+            e1 = rowptr[r + 1];
+            if (long_threshold > 0 && e1 - e0 > long_threshold) live = false;   // split path owns it
+        }
+        if (!live) e1 = e0;
+        for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+            const int col0 = c0 + sub * VEC;
+            const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+            accumulate_edges<T, VEC, LPR>(acc, e0, e1, LPR, sub, col, val, rsrc, ld_bytes, col_off);
+            if (live && col0 < n_feat) store_row<T, VEC>(D + r * ldd, col0, n_feat, acc, relu, vec_store != 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// split path: one wavefront per (long row, edge chunk); fp32 partial rows.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_split_kernel(
+    int n_tasks, int n_feat, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
+    const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes,
+    unsigned ld_bytes, float *__restrict__ partial, int ldp)
+{
+    constexpr int TILE = LPR * VEC;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
+    const int e0 = task_e0[task], e1 = task_e1[task];
+    for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+        const int col0 = c0 + sub * VEC;
+        const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        accumulate_edges<T, VEC, LPR>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, ld_bytes, col_off);
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (col0 + i < n_feat) partial[(int64_t)task * ldp + col0 + i] = acc[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void spmm_split_finalize_kernel(
+    int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
+    const float *__restrict__ partial, int ldp, T *__restrict__ D, int64_t ldd, int relu)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t total = (int64_t)n_long * n_feat;
+    if (gid >= total) return;
+    const int l = (int)(gid / n_feat), j = (int)(gid % n_feat);
+    float s = 0.0f;
+    for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
+    T v = Elem<T>::from_f32(s);
+    D[(int64_t)long_row[l] * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
+}
+
+// ---------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------
+struct LaunchArgs {
+    int relu, n_rows, n_feat;
+    const int32_t *rowptr, *col;
+    const void *val, *H;
+    unsigned h_bytes, ld_bytes;
+    void *D;
+    int64_t ldd;
+    const sgx_plan *plan;
+    float *partial;
+    int ldp;
+    int vec_store;
+    hipStream_t stream;
+};
+
+int grid_for_rows(int64_t n_rows, int rows_per_wave)
+{
+    const int64_t rows_per_block = (int64_t)rows_per_wave * (kBlock / 64);
+    int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+    const int64_t cap = 256 * 64;            // 64 blocks per CU, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <typename T, int VEC, int LPR>
+int launch_one(const LaunchArgs &a)
+{
+    const int long_thr = (a.plan && a.plan->n_long > 0) ? a.plan->long_threshold : 0;
+    hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR>), dim3(grid_for_rows(a.n_rows, 64 / LPR)), dim3(kBlock), 0,
+                       a.stream, a.n_rows, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
+                       a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store);
+    SGX_LAUNCH_CHECK();
+    if (long_thr > 0) {
+        const sgx_plan *p = a.plan;
+        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0, a.stream,
+                           p->n_tasks, a.n_feat, p->task_e0, p->task_e1, a.col, (const T *)a.val, (const T *)a.H,
+                           a.h_bytes, a.ld_bytes, a.partial, a.ldp);
+        SGX_LAUNCH_CHECK();
+        const int64_t total = (int64_t)p->n_long * a.n_feat;
+        hipLaunchKernelGGL((spmm_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, a.partial,
+                           a.ldp, (T *)a.D, a.ldd, a.relu);
+        SGX_LAUNCH_CHECK();
+    }
+    return SGX_OK;
+}
+
+template <typename T, int VEC>
+int launch_lpr(const LaunchArgs &a, int lpr)
+{
+    switch (lpr) {
+    case 1: return launch_one<T, VEC, 1>(a);
+    case 2: return launch_one<T, VEC, 2>(a);
+    case 4: return launch_one<T, VEC, 4>(a);
+    case 8: return launch_one<T, VEC, 8>(a);
+    case 16: return launch_one<T, VEC, 16>(a);
+    case 32: return launch_one<T, VEC, 32>(a);
+    default: return launch_one<T, VEC, 64>(a);
+    }
+}
+
+}  // namespace
+
+size_t sgx_spmm_scratch_bytes(const sgx_plan *plan, int n_feat)
+{
+    if (!plan || plan->n_tasks == 0 || n_feat <= 0) return 0;
+    return sgx_align_up((size_t)plan->n_tasks * (size_t)sgx_align_up((size_t)n_feat, 4) * sizeof(float), 256);
+}
+
+int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,
+                    const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                    const void *H, int64_t ldh, void *D, int64_t ldd,
+                    const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    (void)spmm_block;
+    if (n_rows < 0 || n_cols < 0 || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
+    if (n_rows == 0) return SGX_OK;
+    if (!rowPtr || !D) return SGX_ERR_NULL;
+    if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
+    if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
+    const size_t es = sgx_elem_size(dtype);
+    const unsigned long long table_bytes = (unsigned long long)n_cols * (unsigned long long)ldh * es;
+    if (table_bytes >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;      // 32-bit buffer offsets
+    if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
+
+    LaunchArgs a;
+    a.relu = relu; a.n_rows = n_rows; a.n_feat = n_feat;
+    a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.H = H;
+    a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
+    a.D = D; a.ldd = ldd; a.plan = plan; a.stream = stream;
+    a.partial = (float *)scratch;
+    a.ldp = (int)sgx_align_up((size_t)n_feat, 4);
+    if (plan && plan->n_tasks > 0) {
+        if (!scratch || scratch_bytes < sgx_spmm_scratch_bytes(plan, n_feat)) return SGX_ERR_WORKSPACE;
+    }
+    const int per16 = (int)(16 / es);
+    const bool vec_gather = ((uintptr_t)H % 16 == 0) && ((ldh * es) % 16 == 0);
+    a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
+    if (vec_gather) {
+        const int lpr = sgx_next_pow2((n_feat + per16 - 1) / per16);
+        return dtype == SGX_F16 ? launch_lpr<f16, 8>(a, lpr > 64 ? 64 : lpr)
+                                : launch_lpr<float, 4>(a, lpr > 64 ? 64 : lpr);
+    }
+    const int lpr = sgx_next_pow2(n_feat);
+    return dtype == SGX_F16 ? launch_lpr<f16, 1>(a, lpr > 64 ? 64 : lpr)
+                            : launch_lpr<float, 1>(a, lpr > 64 ? 64 : lpr);
+}
+
+extern "C" int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,
+                            const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                            const void *H, int64_t ldh, void *D, int64_t ldd,
+                            const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
+{
+    return sgx_spmm_launch(dtype, acc_mode, spmm_block, relu, n_rows, n_cols, n_feat, rowPtr, columnIndex, values,
+                           H, ldh, D, ldd, plan, scratch, scratch_bytes, (hipStream_t)stream);
+}

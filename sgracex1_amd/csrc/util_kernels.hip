@@ -1,0 +1,216 @@
+// Small kernels on either side of the hot path: weight-tile transpose (K.cpp:3038-3051),
+// CSR validation (new: the reference validates nothing), COO -> CSR row pointer for the
+// COO staging of the GAT host code (SG.py:1222, :1245), the ReLU mask of RPYNQ.backward
+// (MOL cell 16), and the row schedule (sgx_plan).
+#include "sgx_internal.h"
+
+#include <vector>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void transpose_kernel(int rows, int cols, const T *__restrict__ in, int64_t ldi,
+                                                           T *__restrict__ out, int64_t ldo)
+{
+    // out[c][r] = in[r][c]; 32x32 tile through LDS so that both sides are coalesced
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * ldi + c] : (T)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;                           // out row c, out column r
+        if (c < cols && r < ldo) out[(int64_t)c * ldo + r] = (r < rows) ? tile[tx][i] : (T)0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void csr_validate_kernel(const int32_t *__restrict__ rowptr,
+                                                              const int32_t *__restrict__ col, int n_rows, int n_cols,
+                                                              int64_t nnz, int *__restrict__ bad)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if (gid == 0 && (rowptr[0] != 0 || (int64_t)rowptr[n_rows] != nnz)) atomicOr(bad, 1);
+    for (int64_t r = gid; r < n_rows; r += stride)
+        if (rowptr[r + 1] < rowptr[r]) atomicOr(bad, 2);
+    if (col)
+        for (int64_t e = gid; e < nnz; e += stride)
+            if (col[e] < 0 || col[e] >= n_cols) atomicOr(bad, 4);
+}
+
+// rowPtr[r] = number of edges with row index < r  (rowIndex sorted ascending)
+__global__ __launch_bounds__(kBlock) void coo_to_csr_kernel(const int32_t *__restrict__ row, int64_t nnz, int n_rows,
+                                                            int32_t *__restrict__ rowptr)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t e = gid; e <= nnz; e += stride) {
+        const int prev = e == 0 ? -1 : row[e - 1];
+        const int cur = e == nnz ? n_rows : row[e];
+        for (int r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)e;   // every row in (prev, cur] starts at e
+    }
+}
+
+template <typename TO, typename TG>
+__global__ __launch_bounds__(kBlock) void relu_mask_kernel(const TO *__restrict__ out, TG *__restrict__ grad, int64_t n)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = gid; i < n; i += stride)
+        if (out[i] == (TO)0) grad[i] = (TG)0;
+}
+
+int grid_1d(int64_t n)
+{
+    int64_t b = (n + kBlock - 1) / kBlock;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi, void *out, int64_t ldo,
+                             void *stream)
+{
+    if (rows < 0 || cols < 0 || ldi < cols || ldo < rows) return SGX_ERR_SHAPE;
+    if (rows == 0 || cols == 0) return SGX_OK;
+    if (!in || !out) return SGX_ERR_NULL;
+    // grid.y covers ldo so that the pad columns rows..ldo-1 are zeroed too
+    dim3 grid((cols + 31) / 32, (unsigned)((ldo + 31) / 32));
+    if (dtype == SGX_F16)
+        hipLaunchKernelGGL(transpose_kernel<f16>, grid, dim3(kBlock), 0, (hipStream_t)stream, rows, cols,
+                           (const f16 *)in, ldi, (f16 *)out, ldo);
+    else if (dtype == SGX_F32)
+        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(kBlock), 0, (hipStream_t)stream, rows, cols,
+                           (const float *)in, ldi, (float *)out, ldo);
+    else
+        return SGX_ERR_UNSUPPORTED;
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+extern "C" int sgx_csr_validate(const int32_t *rowPtr, const int32_t *columnIndex, int n_rows, int n_cols, int64_t nnz,
+                                void *stream)
+{
+    if (!rowPtr) return SGX_ERR_NULL;
+    if (n_rows < 0 || n_cols < 0 || nnz < 0) return SGX_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    int *bad = nullptr;
+    SGX_HIP_CHECK(hipMalloc(&bad, sizeof(int)));
+    int host = 0;
+    int rc = SGX_OK;
+    if (hipMemsetAsync(bad, 0, sizeof(int), s) != hipSuccess) rc = SGX_ERR_HIP;
+    if (rc == SGX_OK) {
+        hipLaunchKernelGGL(csr_validate_kernel, dim3(grid_1d(nnz > n_rows ? nnz : n_rows)), dim3(kBlock), 0, s, rowPtr,
+                           columnIndex, n_rows, n_cols, nnz, bad);
+        if (hipGetLastError() != hipSuccess) rc = SGX_ERR_HIP;
+    }
+    if (rc == SGX_OK && hipMemcpyAsync(&host, bad, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) rc = SGX_ERR_HIP;
+    if (rc == SGX_OK && hipStreamSynchronize(s) != hipSuccess) rc = SGX_ERR_HIP;
+    (void)hipFree(bad);
+    if (rc != SGX_OK) return rc;
+    return host ? SGX_ERR_CSR : SGX_OK;
+}
+
+extern "C" int sgx_coo_to_csr(const int32_t *rowIndex, int64_t nnz, int n_rows, int32_t *rowPtr, void *stream)
+{
+    if (!rowPtr || (nnz > 0 && !rowIndex)) return SGX_ERR_NULL;
+    if (nnz < 0 || n_rows < 0) return SGX_ERR_SHAPE;
+    hipLaunchKernelGGL(coo_to_csr_kernel, dim3(grid_1d(nnz + 1)), dim3(kBlock), 0, (hipStream_t)stream, rowIndex, nnz,
+                       n_rows, rowPtr);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n, void *stream)
+{
+    if (n < 0) return SGX_ERR_SHAPE;
+    if (n == 0) return SGX_OK;
+    if (!out || !grad) return SGX_ERR_NULL;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(grid_1d(n)), block(kBlock);
+    if (dtype_out == SGX_F16 && dtype_grad == SGX_F16)
+        hipLaunchKernelGGL((relu_mask_kernel<f16, f16>), grid, block, 0, s, (const f16 *)out, (f16 *)grad, n);
+    else if (dtype_out == SGX_F16 && dtype_grad == SGX_F32)
+        hipLaunchKernelGGL((relu_mask_kernel<f16, float>), grid, block, 0, s, (const f16 *)out, (float *)grad, n);
+    else if (dtype_out == SGX_F32 && dtype_grad == SGX_F32)
+        hipLaunchKernelGGL((relu_mask_kernel<float, float>), grid, block, 0, s, (const float *)out, (float *)grad, n);
+    else if (dtype_out == SGX_F32 && dtype_grad == SGX_F16)
+        hipLaunchKernelGGL((relu_mask_kernel<float, f16>), grid, block, 0, s, (const float *)out, (f16 *)grad, n);
+    else
+        return SGX_ERR_UNSUPPORTED;
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Row schedule.  Built on the host from one device->host copy of rowPtr: the graph is fixed
+// across layers and epochs (the reference re-streams the same CSR for every tile and layer),
+// so this runs once per adjacency.
+// ---------------------------------------------------------------------------------------
+static const int kLongThreshold = 512;   // rows with more edges than this take the split path
+static const int kChunk = 512;           // edges per split task (8 pieces of 64 edges per wavefront)
+
+extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows, int n_feat_hint, void *stream)
+{
+    (void)n_feat_hint;
+    if (!out || !rowPtr) return SGX_ERR_NULL;
+    if (n_rows < 0) return SGX_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int32_t> rp((size_t)n_rows + 1);
+    SGX_HIP_CHECK(hipMemcpyAsync(rp.data(), rowPtr, sizeof(int32_t) * ((size_t)n_rows + 1), hipMemcpyDeviceToHost, s));
+    SGX_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<int32_t> long_row, long_first, task_row, task_e0, task_e1;
+    for (int r = 0; r < n_rows; ++r) {
+        const int deg = rp[r + 1] - rp[r];
+        if (deg <= kLongThreshold) continue;
+        long_row.push_back(r);
+        long_first.push_back((int32_t)task_row.size());
+        for (int e = rp[r]; e < rp[r + 1]; e += kChunk) {
+            task_row.push_back(r);
+            task_e0.push_back(e);
+            task_e1.push_back(e + kChunk < rp[r + 1] ? e + kChunk : rp[r + 1]);
+        }
+    }
+    long_first.push_back((int32_t)task_row.size());
+    sgx_plan *p = new sgx_plan();
+    p->n_rows = n_rows;
+    p->long_threshold = kLongThreshold;
+    p->chunk = kChunk;
+    p->n_long = (int)long_row.size();
+    p->n_tasks = (int)task_row.size();
+    p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
+    if (p->n_long > 0) {
+        const size_t nl = long_row.size(), nt = task_row.size();
+        int32_t *blob = nullptr;
+        if (hipMalloc(&blob, sizeof(int32_t) * (nl + nl + 1 + 3 * nt)) != hipSuccess) { delete p; return SGX_ERR_HIP; }
+        p->long_row = blob;
+        p->long_first = blob + nl;
+        p->task_row = p->long_first + nl + 1;
+        p->task_e0 = p->task_row + nt;
+        p->task_e1 = p->task_e0 + nt;
+        bool ok = hipMemcpy(p->long_row, long_row.data(), 4 * nl, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(p->long_first, long_first.data(), 4 * (nl + 1), hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(p->task_row, task_row.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(p->task_e0, task_e0.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(p->task_e1, task_e1.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) { (void)hipFree(blob); delete p; return SGX_ERR_HIP; }
+    }
+    *out = p;
+    return SGX_OK;
+}
+
+extern "C" void sgx_plan_destroy(sgx_plan *plan)
+{
+    if (!plan) return;
+    if (plan->long_row) (void)hipFree(plan->long_row);     // one blob, long_row is its base
+    delete plan;
+}
+
+extern "C" int sgx_plan_long_rows(const sgx_plan *plan) { return plan ? plan->n_long : 0; }

@@ -1,0 +1,213 @@
+// Dense feature x weight product  H = X . W  on the gfx950 matrix cores -- the X.W stage of the
+// reference in gemm_mode 1 (loop_fea / compute1 / dsp_kernel_wrapper_fea with rnnz = M_fea,
+// K.cpp:2932, :2605, :847-865, :985-1012).
+//
+// Shapes are skinny (M_fea 7..602, P 2..256, n_rows up to millions), so the kernel is bound by
+// streaming X once from HBM and writing H once; W^T (= the reference's B buffer, [P][M_fea],
+// K contiguous) stays in L2/L1.  Orientation: the MFMA computes the TRANSPOSED tile
+//     H^T[n][m] = sum_k Wt[n][k] * X[m][k]
+// with A := Wt rows and B := X rows, because (a) both operands are then 16 contiguous bytes per
+// lane along K straight from their row-major storage -- no LDS staging, no transposes -- and
+// (b) in the 16x16 C/D layout (col = lane&15 = m, row = 4*(lane>>4)+reg = n) a lane ends up
+// holding 4 consecutive columns n of one row m of H: one 8-byte store per lane.
+//
+// fp16: v_mfma_f32_16x16x32_f16, fp32 accumulate, one rounding to fp16.
+// fp32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).
+#include "sgx_internal.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// 8 consecutive K elements of one row, zero beyond k_end; vector load when the row is 16-byte aligned
+__device__ __forceinline__ f16x8 load_k8(const f16 *__restrict__ row, int k, int k_end, bool row_ok, bool aligned)
+{
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!row_ok) return v;
+    if (aligned && k + 8 <= k_end) return *reinterpret_cast<const f16x8 *>(row + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (k + j < k_end) v[j] = row[k + j];
+    return v;
+}
+
+__device__ __forceinline__ f32x4 load_k4(const float *__restrict__ row, int k, int k_end, bool row_ok, bool aligned)
+{
+    f32x4 v = {0, 0, 0, 0};
+    if (!row_ok) return v;
+    if (aligned && k + 4 <= k_end) return *reinterpret_cast<const f32x4 *>(row + k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k + j < k_end) v[j] = row[k + j];
+    return v;
+}
+
+// One wavefront: MT tiles of 16 rows of X  x  NT tiles of 16 columns of W.
+template <int NT, int MT>
+__global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
+    int n_rows, int M, int P, int p_base, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt, int64_t ldw,
+    f16 *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t row0 = wave * (MT * 16);
+    if (row0 >= n_rows) return;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+
+    for (int k0 = 0; k0 < M; k0 += 32) {
+        const int k = k0 + 8 * lq;
+        f16x8 a[NT], b[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = p_base + nt * 16 + l15;
+            a[nt] = load_k8(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = row0 + mt * 16 + l15;
+            b[mt] = load_k8(X + m * ldx, k, M, m < n_rows, x_aligned);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[nt], b[mt], acc[mt][nt], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = row0 + mt * 16 + l15;
+        if (m >= n_rows) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = p_base + nt * 16 + 4 * lq;       // 4 consecutive columns of H
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
+            f16 *dst = H + m * ldh + n;
+            if (h_aligned && n + 4 <= ldh) {
+                *reinterpret_cast<f16x4 *>(dst) = o;        // columns P..ldh-1 receive exact zeros
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < ldh) dst[j] = o[j];
+            }
+        }
+    }
+}
+
+// fp32: each lane loads 4 consecutive K of its row; MFMA step j consumes element j of both
+// operands, so the four steps together cover k0..k0+15 (any consistent K order sums the same set).
+template <int NT, int MT>
+__global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
+    int n_rows, int M, int P, int p_base, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt,
+    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t row0 = wave * (MT * 16);
+    if (row0 >= n_rows) return;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+
+    for (int k0 = 0; k0 < M; k0 += 16) {
+        const int k = k0 + 4 * lq;
+        f32x4 a[NT], b[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = p_base + nt * 16 + l15;
+            a[nt] = load_k4(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = row0 + mt * 16 + l15;
+            b[mt] = load_k4(X + m * ldx, k, M, m < n_rows, x_aligned);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][j], b[mt][j], acc[mt][nt], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int64_t m = row0 + mt * 16 + l15;
+        if (m >= n_rows) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = p_base + nt * 16 + 4 * lq;
+            float *dst = H + m * ldh + n;
+            if (h_aligned && n + 4 <= ldh) {
+                *reinterpret_cast<f32x4 *>(dst) = acc[mt][nt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < ldh) dst[j] = acc[mt][nt][j];
+            }
+        }
+    }
+}
+
+template <int NT, int MT>
+int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
+                int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s)
+{
+    const int64_t rows_per_block = (int64_t)MT * 16 * (kBlock / 64);
+    const unsigned grid = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
+    if (dtype == SGX_F16)
+        hipLaunchKernelGGL((xw_dense_f16_kernel<NT, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, p_base,
+                           (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, xa, wa, ha);
+    else
+        hipLaunchKernelGGL((xw_dense_f32_kernel<NT, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, p_base,
+                           (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+}  // namespace
+
+extern "C" int sgx_xw_dense(int dtype, int acc_mode, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
+                            const void *Wt, int64_t ldw, void *H, int64_t ldh, void *stream)
+{
+    if (n_rows < 0 || M_fea < 1 || P < 1 || ldx < M_fea || ldw < M_fea || ldh < P) return SGX_ERR_SHAPE;
+    if (n_rows == 0) return SGX_OK;
+    if (!X || !Wt || !H) return SGX_ERR_NULL;
+    if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t es = sgx_elem_size(dtype);
+    const int xa = ((uintptr_t)X % 16 == 0) && ((ldx * es) % 16 == 0);
+    const int wa = ((uintptr_t)Wt % 16 == 0) && ((ldw * es) % 16 == 0);
+    const int ha = ((uintptr_t)H % (4 * es) == 0) && ((ldh * es) % (4 * es) == 0);
+    // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
+    for (int p_base = 0; p_base < ldh; p_base += 256) {
+        const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);
+        const int nt = (cols + 15) / 16;
+        int rc;
+        if (nt <= 1)       rc = launch_tile<1, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        else if (nt <= 2)  rc = launch_tile<2, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        else if (nt <= 4)  rc = launch_tile<4, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        else if (nt <= 8)  rc = launch_tile<8, 2>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        else               rc = launch_tile<16, 1>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        if (rc != SGX_OK) return rc;
+    }
+    return SGX_OK;
+}

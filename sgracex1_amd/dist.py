@@ -1,0 +1,143 @@
+"""Node-partitioned execution of the layer across the GPUs of one node.
+
+Partition: contiguous 1-D row blocks, exactly the reference's thread split with pointer rebasing
+(K.cpp:1378-1382, :3517-3523): rank g owns rows [lo_g, hi_g) of A (CSR slice with its own
+rowptr starting at 0 and GLOBAL column indices), the same rows of X, and a replica of W.
+Per layer:   H_g = X_g . W   ->   exchange rows of H   ->   D_g = act(A_g . H).
+
+Two exchanges (both are the GPU form of compute1_4 replicating its C block to every ADJ
+thread's PIPO, K.cpp:2913-2916, and dsp_kernel_float_adj_4 selecting the block by column,
+K.cpp:217-264):
+  * "allgather": every rank receives every block of H (one RCCL all_gather_into_tensor);
+    A_g keeps global column indices.
+  * "halo": every rank receives only the rows its edges reference.  Preprocessing builds, per
+    (owner, consumer) pair, the sorted unique list of needed rows and remaps A_g's column indices
+    to the compact table [own rows | halo rows grouped by owner]; at run time a gather packs the
+    rows each peer asked for and one all_to_all_single moves them.
+
+The collective runs on torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests).  The local compute is a `Backend`: the HIP library on GPUs; the CPU tests
+inject their own callables to exercise the partition / remap / exchange logic without a GPU.
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def row_partition(n_rows: int, world: int, rowptr: Optional[torch.Tensor] = None):
+    """Boundaries lo[0..world]: equal row counts, or (rowptr given) equal nnz -- the reference
+    splits by row count only (K.cpp:3517-3523); nnz balance is what power-law graphs need."""
+    if rowptr is None:
+        base = n_rows // world
+        bounds = [g * base for g in range(world)] + [n_rows]     # remainder to the last, as K.cpp:3522
+        return bounds
+    nnz = int(rowptr[-1])
+    targets = torch.tensor([nnz * g // world for g in range(1, world)], dtype=rowptr.dtype, device=rowptr.device)
+    cuts = torch.searchsorted(rowptr.contiguous(), targets).tolist()
+    return [0] + [min(int(c), n_rows) for c in cuts] + [n_rows]
+
+
+def slice_rows(rowptr, col, val, lo, hi):
+    """Rows [lo, hi) of a CSR matrix with the row pointer rebased to 0 (reada2, K.cpp:1378-1382)."""
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    return (rowptr[lo:hi + 1] - rowptr[lo]).contiguous(), col[e0:e1].contiguous(), val[e0:e1].contiguous()
+
+
+@dataclass
+class HaloPlan:
+    """Index structures of the halo exchange for one rank (all tensors on the compute device)."""
+    bounds: List[int]                 # row partition, len world+1
+    rank: int
+    col_compact: torch.Tensor         # int32 [nnz_local]: column -> row of the compact table
+    send_rows: torch.Tensor           # int64 [sum send_counts]: LOCAL row ids to pack, grouped by consumer
+    send_counts: List[int]            # rows sent to each peer
+    recv_counts: List[int]            # rows received from each owner
+    n_own: int
+
+    @property
+    def n_table(self):
+        return self.n_own + sum(self.recv_counts)
+
+
+def build_halo_plan(col_global: torch.Tensor, bounds: List[int], rank: int, group=None) -> HaloPlan:
+    """Needs one all_to_all of the request lists (preprocessing, once per graph)."""
+    world = len(bounds) - 1
+    lo, hi = bounds[rank], bounds[rank + 1]
+    dev = col_global.device
+    col64 = col_global.to(torch.int64)
+    b = torch.tensor(bounds, dtype=torch.int64, device=dev)
+    owner = torch.searchsorted(b, col64, right=True) - 1
+    need: List[torch.Tensor] = []                    # per owner: sorted unique global rows this rank reads
+    for g in range(world):
+        need.append(torch.unique(col64[owner == g]) if g != rank else col64.new_empty(0))
+    recv_counts = [int(t.numel()) for t in need]
+    # compact numbering: own rows first (global - lo), then each owner's halo rows in sorted order
+    col_compact = torch.empty_like(col64)
+    own = owner == rank
+    col_compact[own] = col64[own] - lo
+    off = hi - lo
+    for g in range(world):
+        if g == rank or recv_counts[g] == 0:
+            continue
+        m = owner == g
+        col_compact[m] = off + torch.searchsorted(need[g], col64[m])
+        off += recv_counts[g]
+    # tell every owner which of its rows we need
+    counts_out = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
+    counts_in = torch.empty_like(counts_out)
+    dist.all_to_all_single(counts_in, counts_out, group=group)
+    send_counts = [int(c) for c in counts_in.tolist()]
+    req_out = torch.cat(need) if sum(recv_counts) else col64.new_empty(0)
+    req_in = col64.new_empty(sum(send_counts))
+    dist.all_to_all_single(req_in, req_out, output_split_sizes=send_counts, input_split_sizes=recv_counts, group=group)
+    return HaloPlan(bounds, rank, col_compact.to(torch.int32), (req_in - lo).contiguous(), send_counts, recv_counts,
+                    hi - lo)
+
+
+@dataclass
+class Backend:
+    """Local compute: xw(fea_local, Wt) -> H_local [n_local, P];  spmm(adj_csr, table, relu) -> D_local."""
+    xw: Callable
+    spmm: Callable
+
+
+def hip_backend():
+    from . import ops
+
+    def xw(fea, Wt):
+        if isinstance(fea, ops.Csr):
+            W = ops.transpose(Wt, ldo=Wt.shape[0])                    # B [P, M] -> W [M, P]
+            return ops.spmm(fea, W, relu=False)
+        return ops.xw_dense(fea, Wt)
+
+    return Backend(xw=xw, spmm=lambda adj, table, relu: ops.spmm(adj, table, relu=relu))
+
+
+def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None):
+    """adj_local: rows of this rank, GLOBAL column indices.  Returns D_local."""
+    world = len(bounds) - 1
+    h_local = backend.xw(fea_local, Wt)
+    sizes = [bounds[g + 1] - bounds[g] for g in range(world)]
+    P = h_local.shape[1]
+    if h_global is None:
+        h_global = torch.empty((bounds[-1], P), dtype=h_local.dtype, device=h_local.device)
+    if len(set(sizes)) == 1:
+        dist.all_gather_into_tensor(h_global, h_local.contiguous(), group=group)
+    else:
+        dist.all_gather(list(h_global.split(sizes)), h_local.contiguous(), group=group)
+    return backend.spmm(adj_local, h_global, relu)
+
+
+def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPlan, group=None, table=None):
+    """adj_compact: rows of this rank with column indices already remapped by build_halo_plan."""
+    h_local = backend.xw(fea_local, Wt)
+    P = h_local.shape[1]
+    if table is None:
+        table = torch.empty((plan.n_table, P), dtype=h_local.dtype, device=h_local.device)
+    table[:plan.n_own] = h_local
+    packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
+    dist.all_to_all_single(table[plan.n_own:], packed, output_split_sizes=plan.recv_counts,
+                           input_split_sizes=plan.send_counts, group=group)
+    return backend.spmm(adj_compact, table, relu)

@@ -1,0 +1,259 @@
+"""Torch-facing wrappers over the C ABI (include/sgx.h).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every function passes raw
+device pointers to libsgx.so and returns torch tensors that alias buffers the call filled.
+All tensors must live on a ROCm device ("cuda"); nothing in this module computes on the CPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import SGX_ACC_F32, SGX_ACC_REF_HALF, SGX_F16, SGX_F32, LayerDesc, check, lib
+
+_DTYPES = {torch.float16: SGX_F16, torch.float32: SGX_F32}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise TypeError(f"sgx supports float16 and float32 element types, got {dtype}") from None
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a tensor on the GPU (got {type(t).__name__}"
+                         f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)})")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _dev2d(t, name):
+    """2-D tensor whose rows may be padded (row stride >= width, unit column stride)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name} must be a tensor on the GPU")
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name} must be 2-D with unit column stride")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch per (device, stream); the library itself never allocates."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+class Plan:
+    """Row schedule of one CSR matrix (sgx_plan): which rows are split across wavefronts."""
+
+    def __init__(self, rowptr, n_feat_hint=64):
+        _dev(rowptr, "rowptr")
+        h = ctypes.c_void_p()
+        check(lib.sgx_plan_create(ctypes.byref(h), _ptr(rowptr), rowptr.numel() - 1, n_feat_hint, _stream()),
+              "sgx_plan_create")
+        self._h = h
+        self.n_rows = rowptr.numel() - 1
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def long_rows(self):
+        return lib.sgx_plan_long_rows(self._h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.sgx_plan_destroy(h)
+
+
+class Csr:
+    """CSR matrix in HBM: rowptr[int32, n_rows+1], col[int32, nnz], val[f16|f32, nnz]."""
+
+    def __init__(self, rowptr, col, val, n_cols, plan=None):
+        self.rowptr = _dev(rowptr, "rowptr")
+        self.col = _dev(col, "col")
+        self.val = _dev(val, "val")
+        if rowptr.dtype != torch.int32 or col.dtype != torch.int32:
+            raise TypeError("CSR indices must be int32 (the reference's `int` ports, K.cpp:3769-3773)")
+        self.n_rows = rowptr.numel() - 1
+        self.n_cols = int(n_cols)
+        self._plan = plan
+
+    @property
+    def nnz(self):
+        return self.col.numel()
+
+    @property
+    def plan(self):
+        if self._plan is None:
+            self._plan = Plan(self.rowptr)
+        return self._plan
+
+    def to(self, dtype):
+        return self if self.val.dtype == dtype else Csr(self.rowptr, self.col, self.val.to(dtype), self.n_cols,
+                                                        self._plan)
+
+    def validate(self):
+        check(lib.sgx_csr_validate(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, self.nnz, _stream()),
+              "sgx_csr_validate")
+
+    @staticmethod
+    def from_dense(dense, dtype=None):
+        """Same CSR torch's `_to_sparse_csr()` yields in the molecule notebook (MOL cell 18)."""
+        sp = dense.to_sparse_csr()
+        val = sp.values() if dtype is None else sp.values().to(dtype)
+        return Csr(sp.crow_indices().to(torch.int32).contiguous(), sp.col_indices().to(torch.int32).contiguous(),
+                   val.contiguous(), dense.shape[1])
+
+    @staticmethod
+    def from_coo(row, col, val, n_rows, n_cols):
+        """Edges sorted by row (SG.py ships COO: rowPtr_adj_buffer holds row indices, SG.py:1245)."""
+        _dev(row, "row")
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=row.device)
+        check(lib.sgx_coo_to_csr(_ptr(row.to(torch.int32).contiguous()), row.numel(), n_rows, _ptr(rowptr), _stream()),
+              "sgx_coo_to_csr")
+        return Csr(rowptr, col.to(torch.int32).contiguous(), val.contiguous(), n_cols)
+
+
+def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True):
+    """D = act(A @ H[:, :n_feat]) -- the aggregation stage alone (sgx_spmm_csr)."""
+    _dev2d(H, "H")
+    code = dtype_code(H.dtype)
+    if adj.val.dtype != H.dtype:
+        raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
+    n_feat = H.shape[1] if n_feat is None else n_feat
+    if out is None:
+        out = torch.empty((adj.n_rows, n_feat), dtype=H.dtype, device=H.device)
+    plan = adj.plan if use_plan else None
+    sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
+    scratch = _workspace(H.device, sbytes) if sbytes else None
+    check(lib.sgx_spmm_csr(code, SGX_ACC_F32, 1, int(bool(relu)), adj.n_rows, H.shape[0], n_feat,
+                           _ptr(adj.rowptr), _ptr(adj.col), _ptr(adj.val), _ptr(H), H.stride(0),
+                           _ptr(out), out.stride(0), plan.handle if plan is not None else None,
+                           _ptr(scratch), sbytes, _stream()), "sgx_spmm_csr")
+    return out
+
+
+def xw_dense(X, Wt, ldh=None):
+    """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M]."""
+    _dev2d(X, "X")
+    _dev2d(Wt, "Wt")
+    code = dtype_code(X.dtype)
+    P, M = Wt.shape
+    per16 = 8 if code == SGX_F16 else 4
+    ldh = (P + per16 - 1) // per16 * per16 if ldh is None else ldh
+    H = torch.empty((X.shape[0], ldh), dtype=X.dtype, device=X.device)
+    check(lib.sgx_xw_dense(code, SGX_ACC_F32, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0),
+                           _ptr(H), ldh, _stream()), "sgx_xw_dense")
+    return H[:, :P]
+
+
+def transpose(x, ldo=None):
+    _dev(x, "x")
+    rows, cols = x.shape
+    ldo = rows if ldo is None else ldo
+    out = torch.empty((cols, ldo), dtype=x.dtype, device=x.device)
+    check(lib.sgx_transpose(dtype_code(x.dtype), rows, cols, _ptr(x), x.stride(0), _ptr(out), ldo, _stream()),
+          "sgx_transpose")
+    return out
+
+
+def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
+                  acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None):
+    """One fused layer  D = act(A . (X . W))  through sgx_layer_forward.
+
+    adj : Csr [N, M_adj];  fea : Csr [M_adj, M_fea] (gemm_mode 0) or dense tensor (gemm_mode 1);
+    Wt  : [P, M_fea] -- the weights TRANSPOSED, what the reference writes into B_buffer.
+    Returns D [N, P] (and (E, S) per-edge tensors when want_edge_outputs with GAT).
+    """
+    _dev(Wt, "Wt")
+    code = dtype_code(Wt.dtype)
+    P, M_fea = Wt.shape
+    d = LayerDesc()
+    gemm_mode = 0 if isinstance(fea, Csr) else 1
+    d.gemm_mode, d.relu, d.gat_mode = gemm_mode, int(bool(relu)), int(gat_attention is not None)
+    d.N_adj, d.M_adj, d.M_fea, d.P_w = adj.n_rows, adj.n_cols, M_fea, P
+    d.bias_count, d.dtype, d.acc_mode, d.spmm_block = bias_count, code, acc_mode, spmm_block
+    if adj.val.dtype != Wt.dtype:
+        raise TypeError("adjacency, features and weights must share one element type (MM.h:129-139)")
+    if gemm_mode == 0:
+        if fea.val.dtype != Wt.dtype or fea.n_rows != adj.n_cols or fea.n_cols != M_fea:
+            raise ValueError("feature CSR does not match adjacency / weights")
+        d.rowPtr_fea, d.columnIndex_fea, d.values_fea = (fea.rowptr.data_ptr(), fea.col.data_ptr(),
+                                                         fea.val.data_ptr())
+        if use_plan:
+            d.plan_fea = fea.plan.handle
+    else:
+        _dev(fea, "fea")
+        if fea.dtype != Wt.dtype or fea.shape != (adj.n_cols, M_fea):
+            raise ValueError(f"dense features must be [{adj.n_cols}, {M_fea}] {Wt.dtype}")
+        d.values_fea = fea.data_ptr()
+    d.rowPtr_adj, d.columnIndex_adj, d.values_adj = adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr()
+    if use_plan:
+        d.plan_adj = adj.plan.handle
+    d.B = Wt.data_ptr()
+    if out is None:
+        out = torch.empty((adj.n_rows, P), dtype=Wt.dtype, device=Wt.device)
+    d.D = out.data_ptr()
+    E = S = None
+    if gat_attention is not None:
+        att = _dev(gat_attention, "attention").reshape(-1)
+        if att.numel() != 2 * P or att.dtype != Wt.dtype:
+            raise ValueError("attention must hold 2*P_w elements of the layer dtype")
+        d.attention, d.alpha = att.data_ptr(), float(alpha)
+        if want_edge_outputs:
+            E = torch.empty(adj.nnz, dtype=torch.float32, device=Wt.device)
+            S = torch.empty(adj.nnz, dtype=torch.float32, device=Wt.device)
+            d.E, d.S = E.data_ptr(), S.data_ptr()
+    if agg_events is not None:          # (begin, end) hipEvent_t handles, see hipevents.py
+        d.ev_agg_begin, d.ev_agg_end = agg_events
+    nbytes = lib.sgx_layer_workspace_bytes(ctypes.byref(d))
+    ws = _workspace(Wt.device, nbytes)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.sgx_layer_forward(ctypes.byref(d), _stream()), "sgx_layer_forward")
+    return (out, E, S) if want_edge_outputs else out
+
+
+def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False):
+    _dev2d(Wh, "Wh")
+    code = dtype_code(Wh.dtype)
+    N, F = Wh.shape
+    att = _dev(attention, "attention").reshape(-1)
+    out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
+    E = S = None
+    if want_edge_outputs:
+        E = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
+        S = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
+    s = torch.empty(2 * N, dtype=torch.float32, device=Wh.device)
+    check(lib.sgx_gat_aggregate(code, int(bool(relu)), adj.n_rows, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
+                                _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
+                                _ptr(E), _ptr(S), _ptr(s), _stream()), "sgx_gat_aggregate")
+    return (out, E, S) if want_edge_outputs else out
+
+
+def relu_mask_backward_(out, grad):
+    """grad[out == 0] = 0 in place (RPYNQ.backward, MOL cell 16)."""
+    _dev(out, "out")
+    _dev(grad, "grad")
+    check(lib.sgx_relu_mask_backward(dtype_code(out.dtype), _ptr(out), dtype_code(grad.dtype), _ptr(grad),
+                                     out.numel(), _stream()), "sgx_relu_mask_backward")
+    return grad

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports exactly what
+include/sgx.h declares, the ctypes struct mirrors the header, and argument validation answers
+with the documented status codes without touching a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sgx.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from sgracex1_amd import build
+    build.build()
+    from sgracex1_amd import _lib
+    return _lib
+
+
+def _header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(L):
+    declared = _header_functions()
+    assert declared == sorted(L.SYMBOLS)
+    for name in declared:
+        assert hasattr(L.lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (sgx_[a-z0-9_]+)", out))
+    assert exported == set(declared)
+
+
+def test_header_compiles_as_c_and_struct_layout_matches(L, tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "sgx.h"\n'
+        "int main(void){\n"
+        ' printf("%zu\\n", sizeof(sgx_layer_desc));\n'
+        + "".join(f' printf("{name} %zu\\n", offsetof(sgx_layer_desc, {name}));\n' for name, _ in L.LayerDesc._fields_)
+        + " return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)], text=True).split("\n")
+    assert int(lines[0]) == ctypes.sizeof(L.LayerDesc)
+    for ln in lines[1:]:
+        if ln:
+            name, off = ln.split()
+            assert getattr(L.LayerDesc, name).offset == int(off), name
+
+
+def test_version_and_status_strings(L):
+    assert L.lib.sgx_version() == 100
+    assert L.status_string(0) == "ok"
+    for code in range(-7, 0):
+        assert L.status_string(code) != "unknown status"
+    assert L.status_string(-99) == "unknown status"
+
+
+def test_argument_checks_need_no_gpu(L):
+    d = L.LayerDesc()
+    assert L.lib.sgx_layer_forward(None, None) == -1                       # SGX_ERR_NULL
+    assert L.lib.sgx_layer_workspace_bytes(ctypes.byref(d)) == 0           # M_fea = 0 -> bad desc
+    d.N_adj, d.M_adj, d.M_fea, d.P_w = 10, 10, 4, 8
+    d.dtype = 7
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3            # SGX_ERR_UNSUPPORTED
+    d.dtype = 0
+    d.gemm_mode = 2                                                        # backward-offload mode: not in the public HLS
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3
+    d.gemm_mode = 1
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -1            # buffers missing
+    # K.cpp:3876-3889: bias_count > 0 returns before computing anything
+    d.bias_count = 3
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == 0
+    d.bias_count = 0
+    need = L.lib.sgx_layer_workspace_bytes(ctypes.byref(d))
+    assert need >= 10 * 8 * 2 and need % 256 == 0
+    assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 0, None, None, None, None, 8, None, 8, None, None, 0, None) == -2
+    assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 8, None, None, None, None, 8, None, 8, None, None, 0, None) == -1
+    assert L.lib.sgx_xw_dense(0, 0, 4, 0, 8, None, 8, None, 8, None, 8, None) == -2
+    assert L.lib.sgx_transpose(0, 4, 4, None, 4, None, 4, None) == -1
+
+
+def test_product_path_has_no_oracle_or_cpu_fallback():
+    """Nothing under sgracex1_amd/ may import or link the oracle."""
+    pkg = os.path.join(ROOT, "sgracex1_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower(), (fn, "mentions the oracle")
+                assert "liborc" not in text

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Tolerances (SURVEY 8c / BASELINE.md): fp16 storage + fp32 accumulation against exact math on
+the same (half-rounded) inputs with H kept in fp16: atol 2e-3, rtol 1e-2 -- the band the
+reference's own half kernel sits in; in practice the device lands ~10x tighter, which the
+tests also assert where the summation order cannot matter.  fp32: rtol 1e-5 (scaled by the
+row's |sum|).  CSR structure and helpers: bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _fixtures import SHAPES, half_ulp_distance, known_answers, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sgx():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from sgracex1_amd import ops
+    return ops
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+def _csr(sgx, csr, n_cols, dtype):
+    rp, ci, va = csr
+    return sgx.Csr(_dev(rp.astype(np.int32)), _dev(ci.astype(np.int32)), _dev(va.astype(np.float32), dtype), n_cols)
+
+
+def _h(oracle, a):
+    """round to half and back: the values the fp16 device path actually sees"""
+    return oracle.to_half(np.asarray(a, np.float32)).astype(np.float32)
+
+
+def _rand_csr(rng, n_rows, n_cols, avg_deg, empty_frac=0.2, long_rows=()):
+    deg = rng.poisson(avg_deg, n_rows)
+    deg[rng.random(n_rows) < empty_frac] = 0
+    for r, d in long_rows:
+        deg[r] = d
+    deg = np.minimum(deg, n_cols)
+    rp = np.zeros(n_rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = np.concatenate([np.sort(rng.choice(n_cols, d, replace=False)) for d in deg] + [np.zeros(0, np.int64)])
+    va = rng.standard_normal(rp[-1]).astype(np.float32)
+    return rp, ci.astype(np.int32), va
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["test", "test2", "mol", "cora", "citeseer"])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_layer_fp16_reference_matrices(sgx, oracle, name, relu):
+    d = load(name)
+    adj_h = (d["adj"][0], d["adj"][1], _h(oracle, d["adj"][2]))
+    fea_h = (d["fea"][0], d["fea"][1], _h(oracle, d["fea"][2]))
+    Wt_h = _h(oracle, d["Wt"])
+    want = oracle.layer_f64(0, relu, adj_h, fea_h, Wt_h, h_round=2)
+    A = _csr(sgx, d["adj"], d["N"], torch.float16)
+    X = _csr(sgx, d["fea"], d["M_fea"], torch.float16)
+    got = sgx.layer_forward(A, X, _dev(d["Wt"], torch.float16), relu=relu)
+    torch.cuda.synchronize()
+    got = got.float().cpu().numpy()
+    assert got.shape == (d["N"], d["P"])
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-3)
+    # fp32 accumulation + one rounding: within 1 half ulp of the rounded exact value, except
+    # where H's own rounding tips a tie; allow 2 ulp and require >= 99% exact
+    ulp = half_ulp_distance(got.astype(np.float16), want.astype(np.float16))
+    assert ulp.max() <= 2 and (ulp == 0).mean() > 0.99
+
+
+def test_layer_known_answers_fp16(sgx, oracle):
+    """The device path against the numbers the reference recorded (csim log / hardware row):
+    its fp32-accumulated result must sit within 2e-3 of every logged half value."""
+    d = load("citeseer")
+    ka = known_answers()
+    A = _csr(sgx, d["adj"], d["N"], torch.float16)
+    X = _csr(sgx, d["fea"], d["M_fea"], torch.float16)
+    got = sgx.layer_forward(A, X, _dev(d["Wt"], torch.float16), relu=0).float().cpu().numpy()
+    for r in ("0", "31"):
+        want = np.array([float(t) for t in ka["csim_log"][r]])
+        np.testing.assert_allclose(got[int(r)], want, rtol=1e-2, atol=2e-3)
+    hw = np.array([float(t) for t in ka["hw_row0_fp16_P16"]])
+    np.testing.assert_allclose(got[0, :16], hw, rtol=1e-2, atol=2e-3)
+    k = load("test")
+    A = _csr(sgx, k["adj"], 4, torch.float16)
+    X = _csr(sgx, k["fea"], 4, torch.float16)
+    out = sgx.layer_forward(A, X, _dev(k["Wt"], torch.float16)).float().cpu().numpy()
+    assert np.array_equal(out, np.array(ka["test_kat"]["D"], np.float32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_layer_dense_features_mol(sgx, oracle, dtype):
+    """gemm_mode 1 (dense X on the matrix cores) == gemm_mode 0 on the one-hot mol features."""
+    d = load("mol")
+    rnd = (lambda a: _h(oracle, a)) if dtype == torch.float16 else (lambda a: np.asarray(a, np.float32))
+    want = oracle.layer_f64(1, 1, (d["adj"][0], d["adj"][1], rnd(d["adj"][2])), rnd(d["fea_dense"]), rnd(d["Wt"]),
+                            h_round=2 if dtype == torch.float16 else 1)
+    A = _csr(sgx, d["adj"], d["N"], dtype)
+    Wt = _dev(d["Wt"], dtype)
+    dense = sgx.layer_forward(A, _dev(d["fea_dense"], dtype), Wt, relu=1)
+    sparse = sgx.layer_forward(A, _csr(sgx, d["fea"], d["M_fea"], dtype), Wt, relu=1)
+    assert torch.equal(dense, sparse)               # one nonzero per row: both orders are exact
+    tol = dict(rtol=1e-2, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dense.float().cpu().numpy(), want, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("P", [1, 2, 7, 8, 21, 24, 64, 100, 128, 256, 520])
+def test_spmm_ragged_shapes(sgx, oracle, dtype, P):
+    """Empty rows, a row count that is not a multiple of the rows per wavefront, every lane
+    grouping (LPR 1..64), the scalar path (odd P) and the column-tile loop (P > 512)."""
+    rng = np.random.default_rng(P)
+    n_rows, n_cols = 1003, 777
+    rp, ci, va = _rand_csr(rng, n_rows, n_cols, 9.0)
+    H = rng.standard_normal((n_cols, P)).astype(np.float32)
+    if dtype == torch.float16:
+        va, H = _h(oracle, va), _h(oracle, H)
+    want = oracle.spmm_f32(1, (rp, ci, va), H.astype(np.float64).astype(np.float32))
+    exact = np.maximum(_dense(rp, ci, va, n_rows, n_cols).astype(np.float64) @ H.astype(np.float64), 0)
+    A = _csr(sgx, (rp, ci, va), n_cols, dtype)
+    got = sgx.spmm(A, _dev(H, dtype), relu=True).float().cpu().numpy()
+    assert not got[np.diff(rp) == 0].any()                          # empty rows are exactly +0
+    scale = np.abs(_dense(rp, ci, np.abs(va), n_rows, n_cols)) @ np.abs(H) + 1e-30
+    if dtype == torch.float16:
+        np.testing.assert_allclose(got, exact, rtol=2e-3, atol=2e-3)
+    else:
+        assert (np.abs(got - exact) / scale).max() < 1e-5
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-3)
+
+
+def _dense(rp, ci, va, n_rows, n_cols):
+    out = np.zeros((n_rows, n_cols), np.float32)
+    rows = np.repeat(np.arange(n_rows), np.diff(rp))
+    np.add.at(out, (rows, ci), va)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_spmm_long_rows_split_path(sgx, oracle, dtype):
+    """Rows longer than the plan's threshold are summed by several wavefronts; with and
+    without a plan the results agree to rounding and both match the exact sum."""
+    rng = np.random.default_rng(7)
+    n_rows, n_cols, P = 300, 6000, 64
+    rp, ci, va = _rand_csr(rng, n_rows, n_cols, 6.0, long_rows=[(0, 513), (17, 5000), (299, 1500), (150, 512)])
+    va *= 0.05
+    H = rng.standard_normal((n_cols, P)).astype(np.float32)
+    if dtype == torch.float16:
+        va, H = _h(oracle, va), _h(oracle, H)
+    exact = _dense(rp, ci, va, n_rows, n_cols).astype(np.float64) @ H.astype(np.float64)
+    A = _csr(sgx, (rp, ci, va), n_cols, dtype)
+    assert A.plan.long_rows == 3                                    # 513, 5000, 1500 (512 is not long)
+    with_plan = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=True).float().cpu().numpy()
+    no_plan = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=False).float().cpu().numpy()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(with_plan, exact, **tol)
+    np.testing.assert_allclose(no_plan, exact, **tol)
+    short = np.diff(rp) <= 512
+    assert np.array_equal(with_plan[short], no_plan[short])         # untouched rows: same kernel, same bits
+    again = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=True).float().cpu().numpy()
+    assert np.array_equal(with_plan, again)                         # split sums are order-fixed
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("M,P", [(7, 64), (64, 64), (100, 256), (602, 128), (33, 21), (64, 7), (1433, 16), (40, 300)])
+def test_xw_dense_mfma(sgx, oracle, dtype, M, P):
+    rng = np.random.default_rng(M * 1000 + P)
+    n = 1037
+    X = rng.standard_normal((n, M)).astype(np.float32)
+    W = (rng.standard_normal((M, P)) / np.sqrt(M)).astype(np.float32)
+    if dtype == torch.float16:
+        X, W = _h(oracle, X), _h(oracle, W)
+    exact = X.astype(np.float64) @ W.astype(np.float64)
+    got = sgx.xw_dense(_dev(X, dtype), _dev(np.ascontiguousarray(W.T), dtype))
+    assert got.shape == (n, P)
+    got = got.float().cpu().numpy()
+    if dtype == torch.float16:
+        np.testing.assert_allclose(got, exact, rtol=2e-3, atol=2e-3)
+        # one rounding of an fp32 sum: off by more than 1 half ulp only where the terms cancel
+        scale = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)
+        ulp = half_ulp_distance(got.astype(np.float16), exact.astype(np.float16))
+        assert (ulp <= 1).mean() > 0.999 and (np.abs(got - exact) <= 1e-3 * scale + 1e-6).all()
+    else:
+        scale = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64)
+        assert (np.abs(got - exact) / scale).max() < 2e-6
+
+
+def test_xw_dense_pad_columns_are_zero(sgx):
+    X = torch.randn(100, 64, device="cuda", dtype=torch.float16)
+    Wt = torch.randn(21, 64, device="cuda", dtype=torch.float16)
+    H = sgx.xw_dense(X, Wt, ldh=24)
+    base = H.as_strided((100, 24), (24, 1))
+    assert not base[:, 21:].any()
+
+
+@pytest.mark.parametrize("name", ["cora", "citeseer"])
+def test_two_layer_forward_fp16(sgx, oracle, name):
+    """Layer 1 sparse X + ReLU, layer 2 dense X (the molecule_gcn / paper configuration)."""
+    d = load(name)
+    g = np.load(__import__("os").path.join(__import__("_fixtures").GOLD, name + ".npz"))
+    W2 = g["w2"].astype(np.float32)
+    adj_h = (d["adj"][0], d["adj"][1], _h(oracle, d["adj"][2]))
+    fea_h = (d["fea"][0], d["fea"][1], _h(oracle, d["fea"][2]))
+    l1 = oracle.layer_f64(0, 1, adj_h, fea_h, _h(oracle, d["Wt"]), h_round=2)
+    l1h = _h(oracle, l1)
+    l2 = oracle.layer_f64(1, 0, adj_h, l1h, _h(oracle, np.ascontiguousarray(W2.T)), h_round=2)
+    A = _csr(sgx, d["adj"], d["N"], torch.float16)
+    X = _csr(sgx, d["fea"], d["M_fea"], torch.float16)
+    o1 = sgx.layer_forward(A, X, _dev(d["Wt"], torch.float16), relu=1)
+    o2 = sgx.layer_forward(A, o1, _dev(np.ascontiguousarray(W2.T), torch.float16), relu=0)
+    np.testing.assert_allclose(o2.float().cpu().numpy(), l2, rtol=1e-2, atol=2e-3)
+
+
+def test_bias_count_quirk(sgx):
+    """K.cpp:3876-3889: bias_count > 0 preloads and returns; D keeps its old contents."""
+    d = load("mol")
+    A = _csr(sgx, d["adj"], d["N"], torch.float16)
+    X = _csr(sgx, d["fea"], d["M_fea"], torch.float16)
+    out = torch.full((d["N"], d["P"]), 7.0, dtype=torch.float16, device="cuda")
+    sgx.layer_forward(A, X, _dev(d["Wt"], torch.float16), out=out, bias_count=1)
+    assert (out == 7).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("F", [8, 32, 64])
+def test_gat_aggregate(sgx, oracle, dtype, F):
+    rng = np.random.default_rng(F)
+    n = 501
+    rp, ci, va = _rand_csr(rng, n, n, 7.0, empty_frac=0.0)
+    # self loops guarantee a positive edge per row, as sym_norm2 does (SG.py:42)
+    dense = _dense(rp, ci, np.abs(va) + 0.1, n, n)
+    dense[np.arange(n), np.arange(n)] = 1.0
+    dense[rng.random((n, n)) < 0.002] = -0.5               # stored but masked out (adj > 0 test)
+    rows, cols = np.nonzero(dense)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    va = dense[rows, cols].astype(np.float32)
+    Wh = rng.standard_normal((n, F)).astype(np.float32)
+    att = (rng.standard_normal(2 * F) * 0.3).astype(np.float32)
+    if dtype == torch.float16:
+        va, Wh, att = _h(oracle, va), _h(oracle, Wh), _h(oracle, att)
+    for relu in (0, 1):
+        D, E, S = oracle.gat_f64(relu, (rp, cols.astype(np.int32), va), Wh, att, 0.2)
+        A = _csr(sgx, (rp, cols.astype(np.int32), va), n, dtype)
+        got, gE, gS = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), alpha=0.2, relu=relu,
+                                        want_edge_outputs=True)
+        tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(got.float().cpu().numpy(), D, **tol)
+        np.testing.assert_allclose(gE.cpu().numpy(), E, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gS.cpu().numpy(), S, rtol=1e-4, atol=1e-6)
+        assert (gS.cpu().numpy()[va <= 0] == 0).all()
+
+
+def test_gat_layer_through_desc(sgx, oracle):
+    d = load("cora")
+    rng = np.random.default_rng(3)
+    att = (rng.standard_normal(2 * d["P"]) * 0.3).astype(np.float32)
+    adj_h = (d["adj"][0], d["adj"][1], _h(oracle, d["adj"][2]))
+    fea_h = (d["fea"][0], d["fea"][1], _h(oracle, d["fea"][2]))
+    _, H = oracle.layer_f64(0, 0, adj_h, fea_h, _h(oracle, d["Wt"]), h_round=2, return_h=True)
+    want, _, _ = oracle.gat_f64(1, adj_h, H, _h(oracle, att), 0.2)
+    A = _csr(sgx, d["adj"], d["N"], torch.float16)
+    X = _csr(sgx, d["fea"], d["M_fea"], torch.float16)
+    got = sgx.layer_forward(A, X, _dev(d["Wt"], torch.float16), relu=1, gat_attention=_dev(att, torch.float16))
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=1e-2, atol=2e-3)
+
+
+def test_helpers_bit_exact(sgx):
+    rng = np.random.default_rng(11)
+    # transpose with padded output
+    x = torch.randn(37, 53, device="cuda", dtype=torch.float16)
+    t = sgx.transpose(x, ldo=40)
+    assert torch.equal(t[:, :37], x.t()) and not t[:, 37:].any()
+    xf = torch.randn(64, 7, device="cuda")
+    assert torch.equal(sgx.transpose(xf), xf.t().contiguous())
+    # COO -> CSR, with empty rows at both ends
+    n = 1000
+    rows = np.sort(rng.integers(5, n - 5, 4000)).astype(np.int32)
+    A = sgx.Csr.from_coo(_dev(rows), _dev(rng.integers(0, n, 4000).astype(np.int32)),
+                         torch.ones(4000, device="cuda", dtype=torch.float16), n, n)
+    want = np.zeros(n + 1, np.int64)
+    want[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    assert np.array_equal(A.rowptr.cpu().numpy(), want)
+    A.validate()
+    # validation catches a broken structure
+    bad = sgx.Csr(A.rowptr.clone(), A.col.clone(), A.val, n)
+    bad.col[5] = n + 3
+    with pytest.raises(RuntimeError):
+        bad.validate()
+    bad = sgx.Csr(A.rowptr.clone(), A.col, A.val, n)
+    bad.rowptr[10] = bad.rowptr[11] + 1
+    with pytest.raises(RuntimeError):
+        bad.validate()
+    # ReLU mask of RPYNQ.backward
+    out = torch.tensor([0.0, 1.0, -0.0, 2.0], device="cuda", dtype=torch.float16)
+    grad = torch.tensor([5.0, 6.0, 7.0, 8.0], device="cuda")
+    sgx.relu_mask_backward_(out, grad)
+    assert grad.tolist() == [0.0, 6.0, 0.0, 8.0]
+
+
+def test_from_dense_matches_torch_csr(sgx):
+    dense = (torch.rand(200, 200, device="cuda") < 0.03).float()
+    A = sgx.Csr.from_dense(dense, torch.float16)
+    sp = dense.to_sparse_csr()
+    assert torch.equal(A.rowptr.long(), sp.crow_indices()) and torch.equal(A.col.long(), sp.col_indices())
