@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/prof_round.sh on the GPU box) into the
+tracked summaries under profiles/:
+
+    profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats, our kernels + top others
+    profiles/<tag>_<workload>_pmc.json           per-launch PMC numbers of the aggregation kernel,
+                                                 the FETCH_SIZE calibration, corrected HBM-side bytes
+    profiles/traffic_latest.json                 what bench.py reports as roofline.traffic
+
+FETCH_SIZE correction (MI355X_MICROARCH.md "HBM" + our own calibration launches): on gfx950 the
+16-byte-per-lane loads (the 128-byte row gathers here, and a streaming copy) are tallied at half
+their bytes; the narrow streams (4-byte colidx, 2-byte values, rowptr) are tallied 1:1.  So
+    read_bytes = 2 * (FETCH_SIZE*1024 - stream_bytes) + stream_bytes ,  write_bytes = WRITE_SIZE*1024.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(pattern):
+    files = glob.glob(pattern)
+    return list(csv.DictReader(open(files[0]))) if files else []
+
+
+def counter(rows, kernel_sub, name):
+    return [float(r["Counter_Value"]) for r in rows if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] == name]
+
+
+def main():
+    tag, wl = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+
+    stats = load(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    keep = [r for r in stats if "GLOBAL__N_1" in r["Name"]] + [r for r in stats if "GLOBAL__N_1" not in r["Name"]][:8]
+    with open(os.path.join(out, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+        w.writeheader()
+        for r in keep:
+            r = dict(r)
+            r["Name"] = r["Name"][:160]
+            w.writerow(r)
+
+    # per-dispatch durations of the aggregation kernel: the A.H launches are the long ones
+    trace = load(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
+                  if "spmm_sblock_kernel" in r["Kernel_Name"])
+    big = [d for d in durs if d > 0.6 * durs[-1]] if durs else []
+    bench_line = None
+    for ln in open(os.path.join(src, "bench_trace.log")):
+        if ln.startswith("{"):
+            bench_line = json.loads(ln)
+
+    K = "spmm_sblock_kernel"
+    fetch = counter(load(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")), K, "FETCH_SIZE")
+    write = counter(load(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv")), K, "WRITE_SIZE")
+    l2 = load(os.path.join(src, "pmc_l2", "*", "*_counter_collection.csv"))
+    hit, miss = counter(l2, K, "TCC_HIT_sum"), counter(l2, K, "TCC_MISS_sum")
+    cal_f = counter(load(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")), K, "FETCH_SIZE")
+    cal_w = counter(load(os.path.join(src, "cal_write", "*", "*_counter_collection.csv")), K, "WRITE_SIZE")
+    cal_copy = counter(load(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")), "copyBuffer", "FETCH_SIZE")
+
+    rl = bench_line["roofline"]
+    cfg = bench_line["config"]
+    nnz, n = cfg["edges_per_gpu"], cfg["nodes_per_gpu"]
+    stream_bytes = nnz * 6 + (n + 1) * 4
+    # the A.H launches are the ones with the largest FETCH_SIZE (the X.W launches of the same
+    # template read a small L2-resident table)
+    f_big = [v for v in fetch if v > 0.6 * max(fetch)]
+    w_big = write[:len(f_big)] if write else []
+    fetch_kb = sum(f_big) / len(f_big)
+    write_kb = sum(w_big) / len(w_big) if w_big else 0.0
+    read_bytes = 2 * (fetch_kb * 1024 - stream_bytes) + stream_bytes
+    write_bytes = write_kb * 1024
+    n_cal = 1 << 24
+    cal_true = n_cal * 128 + n_cal * 6 + (n_cal + 1) * 4
+    summary = {
+        "workload": wl, "tag": tag, "kernel": "spmm_sblock_kernel<f16,8,8> (A.H launches)",
+        "launch_ns_kernel_trace": {"avg": sum(big) / len(big), "min": big[0], "max": big[-1], "n": len(big)},
+        "launch_ms_bench_events": {"avg": rl["avg_launch_ms"], "min": rl["min_launch_ms"]},
+        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+        "TCC_HIT_per_launch": max(hit) if hit else None, "TCC_MISS_per_launch": max(miss) if miss else None,
+        "calibration": {
+            "gather_launch_true_read_bytes": cal_true, "gather_launch_FETCH_SIZE_KB": sum(cal_f) / len(cal_f),
+            "gather_launch_true_write_bytes": n_cal * 128, "gather_launch_WRITE_SIZE_KB": sum(cal_w) / len(cal_w),
+            "copy_2GiB_FETCH_SIZE_KB": max(cal_copy) if cal_copy else None,
+            "reading": "16-byte-per-lane reads counted at 1/2, narrow streams and all writes 1:1",
+        },
+        "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
+        "hbm_side_read_bytes_per_launch": read_bytes, "hbm_side_write_bytes_per_launch": write_bytes,
+        "hbm_bytes_per_launch": read_bytes + write_bytes,
+        "traffic_over_algorithmic": (read_bytes + write_bytes) / rl["algorithmic_bytes_per_launch"],
+        "bench_line": bench_line,
+    }
+    with open(os.path.join(out, f"{tag}_{wl}_pmc.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    with open(os.path.join(out, "traffic_latest.json"), "w") as f:
+        json.dump({"workload": wl, "tag": tag, "hbm_bytes_per_launch": read_bytes + write_bytes,
+                   "source": f"profiles/{tag}_{wl}_pmc.json"}, f, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k not in ("bench_line",)}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
