@@ -162,10 +162,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" is RCCL on ROCm; SGX_DIST_BACKEND=gloo rehearses several ranks on one GPU
+        backend_name = os.environ.get("SGX_DIST_BACKEND", "nccl")
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend_name)
 
     wl = WORKLOADS[args.workload]
     A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device)
@@ -221,10 +226,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        red_dev = device if dist.get_backend() == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([nnz], dtype=torch.int64, device=device)
+        tot = torch.tensor([nnz], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         total_nnz = int(tot.item())
     else:

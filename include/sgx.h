@@ -76,6 +76,10 @@ int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_fe
 void sgx_plan_destroy(sgx_plan *plan);
 /* number of rows that take the split path (for reports / tests) */
 int sgx_plan_long_rows(const sgx_plan *plan);
+/* share of lane-group steps that do work when 8 consecutive rows are packed per wavefront, and
+ * whether the plan therefore schedules the short rows in degree order instead (1) or not (0) */
+float sgx_plan_natural_utilization(const sgx_plan *plan);
+int sgx_plan_reordered(const sgx_plan *plan);
 
 /* ---- the layer: replaces mmult_top / kernelmult1 (K.cpp:3762, :3969; KH:13-58) ------ */
 typedef struct sgx_layer_desc {

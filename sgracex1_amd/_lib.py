@@ -19,7 +19,8 @@ SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
-    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows",
+    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_natural_utilization",
+    "sgx_plan_reordered",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
     "sgx_spmm_csr", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
     "sgx_gat_aggregate", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
@@ -65,6 +66,10 @@ def _load():
     lib.sgx_plan_destroy.restype = None
     lib.sgx_plan_long_rows.argtypes = [vp]
     lib.sgx_plan_long_rows.restype = c_int
+    lib.sgx_plan_natural_utilization.argtypes = [vp]
+    lib.sgx_plan_natural_utilization.restype = ctypes.c_float
+    lib.sgx_plan_reordered.argtypes = [vp]
+    lib.sgx_plan_reordered.restype = c_int
     lib.sgx_layer_workspace_bytes.argtypes = [ctypes.POINTER(LayerDesc)]
     lib.sgx_layer_workspace_bytes.restype = sz
     lib.sgx_layer_forward.argtypes = [ctypes.POINTER(LayerDesc), vp]

@@ -62,3 +62,26 @@ template <> struct Gather<float, 1> {
     }
 };
 
+
+// The same gathers through a 64-bit pointer (tables of 4 GiB and more).
+template <typename T, int VEC> struct GatherPtr;
+template <> struct GatherPtr<f16, 8> {
+    static __device__ __forceinline__ void run(float *acc, float a, const char *p) {
+        Fma<f16, 8>::run(acc, a, *reinterpret_cast<const u32x4 *>(p));
+    }
+};
+template <> struct GatherPtr<float, 4> {
+    static __device__ __forceinline__ void run(float *acc, float a, const char *p) {
+        Fma<float, 4>::run(acc, a, *reinterpret_cast<const u32x4 *>(p));
+    }
+};
+template <> struct GatherPtr<f16, 1> {
+    static __device__ __forceinline__ void run(float *acc, float a, const char *p) {
+        acc[0] = __builtin_fmaf(a, (float)*reinterpret_cast<const f16 *>(p), acc[0]);
+    }
+};
+template <> struct GatherPtr<float, 1> {
+    static __device__ __forceinline__ void run(float *acc, float a, const char *p) {
+        acc[0] = __builtin_fmaf(a, *reinterpret_cast<const float *>(p), acc[0]);
+    }
+};

@@ -38,6 +38,12 @@ struct sgx_plan {
     int32_t *task_row;     // [n_tasks]
     int32_t *task_e0;      // [n_tasks]
     int32_t *task_e1;      // [n_tasks]
+    // Degree-ordered schedule of the rows that are not long (NULL = natural order).  Built only
+    // when packing consecutive rows would leave most lane groups idle (power-law graphs): rows are
+    // bucketed by the number of 8-edge steps they need, longest first, ascending inside a bucket.
+    int32_t *row_order;    // [n_ordered]
+    int n_ordered;
+    float natural_utilization;   // share of lane-group steps doing work when rows are packed in natural order
 };
 
 // leading dimension (elements) the library uses for its own H = X.W scratch: rows are padded

@@ -22,10 +22,13 @@ namespace {
 // Sum of  values[e] * H[columnIndex[e]][col0 : col0+VEC]  over e in [e0, e1) stepping `stride`
 // edges between this group's LPR-edge pieces.  `col_off` = byte offset of this lane's columns
 // inside a row of H, or kOOB when the lane has no valid column.
-template <typename T, int VEC, int LPR>
+// BIG = the table is 4 GiB or larger: buffer offsets are 32 bit, so the gathers become 64-bit
+// global loads under a per-edge predicate (the all-gathered H of an 8-GPU run crosses this size).
+template <typename T, int VEC, int LPR, bool BIG>
 __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int stride, int sub,
                                                  const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                 __amdgpu_buffer_rsrc_t rsrc, unsigned ld_bytes, unsigned col_off)
+                                                 __amdgpu_buffer_rsrc_t rsrc, const T *__restrict__ table,
+                                                 unsigned ld_bytes, unsigned col_off)
 {
     int c_next = 0;
     T a_next = (T)0;
@@ -54,8 +57,14 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
                 const int t = t0 + u;
                 const int cc = __shfl(c, t, LPR);
                 const float aa = __shfl(a, t, LPR);
-                const unsigned off = (t < n && col_off != kOOB) ? (unsigned)cc * ld_bytes + col_off : kOOB;
-                Gather<T, VEC>::run(acc, aa, rsrc, off);
+                const bool valid = t < n && col_off != kOOB;
+                if constexpr (!BIG) {
+                    Gather<T, VEC>::run(acc, aa, rsrc, valid ? (unsigned)cc * ld_bytes + col_off : kOOB);
+                } else {
+                    if (valid)
+                        GatherPtr<T, VEC>::run(acc, aa, reinterpret_cast<const char *>(table) +
+                                                            (size_t)(unsigned)cc * ld_bytes + col_off);
+                }
             }
         }
     }
@@ -84,11 +93,12 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 // ---------------------------------------------------------------------------------------
 // sblock path: one group of LPR lanes per row, 64/LPR rows per wavefront.
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR>
+template <typename T, int VEC, int LPR, bool BIG>
 __global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
-    T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store)
+    T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store,
+    const int32_t *__restrict__ row_order)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
     constexpr int TILE = LPR * VEC;               // columns covered per pass
@@ -100,11 +110,14 @@ __global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
 
+    // n_rows = number of work items; row_order (from the plan) lists the rows in degree order so
+    // that the 64/LPR rows a wavefront owns need about the same number of steps
     for (int64_t r0 = wave * RPW; r0 < n_rows; r0 += n_waves * RPW) {
-        const int64_t r = r0 + grp;
+        int64_t r = r0 + grp;
         int e0 = 0, e1 = 0;
         bool live = r < n_rows;
         if (live) {
+            if (row_order) r = row_order[r];
             e0 = rowptr[r];
             e1 = rowptr[r + 1];
             if (long_threshold > 0 && e1 - e0 > long_threshold) live = false;   // split path owns it
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
             float acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-            accumulate_edges<T, VEC, LPR>(acc, e0, e1, LPR, sub, col, val, rsrc, ld_bytes, col_off);
+            accumulate_edges<T, VEC, LPR, BIG>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, col_off);
             if (live && col0 < n_feat) store_row<T, VEC>(D + r * ldd, col0, n_feat, acc, relu, vec_store != 0);
         }
     }
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
 // ---------------------------------------------------------------------------------------
 // split path: one wavefront per (long row, edge chunk); fp32 partial rows.
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR>
+template <typename T, int VEC, int LPR, bool BIG>
 __global__ __launch_bounds__(kBlock) void spmm_split_kernel(
     int n_tasks, int n_feat, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
     const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes,
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void spmm_split_kernel(
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-        accumulate_edges<T, VEC, LPR>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, ld_bytes, col_off);
+        accumulate_edges<T, VEC, LPR, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes, col_off);
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
@@ -188,6 +201,7 @@ struct LaunchArgs {
     float *partial;
     int ldp;
     int vec_store;
+    bool big;
     hipStream_t stream;
 };
 
@@ -201,17 +215,21 @@ int grid_for_rows(int64_t n_rows, int rows_per_wave)
     return (int)blocks;
 }
 
-template <typename T, int VEC, int LPR>
-int launch_one(const LaunchArgs &a)
+template <typename T, int VEC, int LPR, bool BIG>
+int launch_one_impl(const LaunchArgs &a)
 {
     const int long_thr = (a.plan && a.plan->n_long > 0) ? a.plan->long_threshold : 0;
-    hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR>), dim3(grid_for_rows(a.n_rows, 64 / LPR)), dim3(kBlock), 0,
-                       a.stream, a.n_rows, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
-                       a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store);
-    SGX_LAUNCH_CHECK();
+    const int32_t *order = a.plan ? a.plan->row_order : nullptr;
+    const int n_work = order ? a.plan->n_ordered : a.n_rows;
+    if (n_work > 0) {
+        hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR, BIG>), dim3(grid_for_rows(n_work, 64 / LPR)),
+                           dim3(kBlock), 0, a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val,
+                           (const T *)a.H, a.h_bytes, a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order);
+        SGX_LAUNCH_CHECK();
+    }
     if (long_thr > 0) {
         const sgx_plan *p = a.plan;
-        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0, a.stream,
+        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR, BIG>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0, a.stream,
                            p->n_tasks, a.n_feat, p->task_e0, p->task_e1, a.col, (const T *)a.val, (const T *)a.H,
                            a.h_bytes, a.ld_bytes, a.partial, a.ldp);
         SGX_LAUNCH_CHECK();
@@ -222,6 +240,12 @@ int launch_one(const LaunchArgs &a)
         SGX_LAUNCH_CHECK();
     }
     return SGX_OK;
+}
+
+template <typename T, int VEC, int LPR>
+int launch_one(const LaunchArgs &a)
+{
+    return a.big ? launch_one_impl<T, VEC, LPR, true>(a) : launch_one_impl<T, VEC, LPR, false>(a);
 }
 
 template <typename T, int VEC>
@@ -260,13 +284,14 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
     const size_t es = sgx_elem_size(dtype);
     const unsigned long long table_bytes = (unsigned long long)n_cols * (unsigned long long)ldh * es;
-    if (table_bytes >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;      // 32-bit buffer offsets
+    const bool big = table_bytes >= 0xFFFFFFF0ull;                     // beyond 32-bit buffer offsets
+    if ((unsigned long long)ldh * es >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
     if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
 
     LaunchArgs a;
     a.relu = relu; a.n_rows = n_rows; a.n_feat = n_feat;
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.H = H;
-    a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
+    a.h_bytes = big ? 0u : (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es); a.big = big;
     a.D = D; a.ldd = ldd; a.plan = plan; a.stream = stream;
     a.partial = (float *)scratch;
     a.ldp = (int)sgx_align_up((size_t)n_feat, 4);

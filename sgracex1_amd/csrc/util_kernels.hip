@@ -156,6 +156,7 @@ extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_
 // ---------------------------------------------------------------------------------------
 static const int kLongThreshold = 512;   // rows with more edges than this take the split path
 static const int kChunk = 512;           // edges per split task (8 pieces of 64 edges per wavefront)
+static const float kReorderBelow = 0.7f; // natural-order lane-group utilisation below which rows are degree-ordered
 
 extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows, int n_feat_hint, void *stream)
 {
@@ -202,6 +203,47 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
                   hipMemcpy(p->task_e1, task_e1.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) { (void)hipFree(blob); delete p; return SGX_ERR_HIP; }
     }
+
+    // Would packing 8 consecutive rows per wavefront keep the lane groups busy?  A group needs
+    // ceil(deg/8) steps, the wavefront runs for the largest of its 8 rows.
+    p->row_order = nullptr;
+    p->n_ordered = 0;
+    {
+        const int kGroup = 8, kStepsMax = kLongThreshold / 8 + 1;
+        double useful = 0, spent = 0;
+        for (int r0 = 0; r0 < n_rows; r0 += kGroup) {
+            int mx = 0;
+            for (int r = r0; r < r0 + kGroup && r < n_rows; ++r) {
+                const int deg = rp[r + 1] - rp[r];
+                const int steps = deg > kLongThreshold ? 0 : (deg + 7) / 8;
+                useful += steps;
+                if (steps > mx) mx = steps;
+            }
+            spent += (double)mx * kGroup;
+        }
+        p->natural_utilization = spent > 0 ? (float)(useful / spent) : 1.0f;
+        if (p->natural_utilization < kReorderBelow && n_rows - p->n_long > 0) {
+            // counting sort by step count, longest first, ascending row id inside a bucket
+            std::vector<int64_t> start(kStepsMax + 1, 0);
+            for (int r = 0; r < n_rows; ++r) {
+                const int deg = rp[r + 1] - rp[r];
+                if (deg <= kLongThreshold) start[(deg + 7) / 8]++;
+            }
+            int64_t acc = 0;
+            for (int b = kStepsMax; b >= 0; --b) { const int64_t c = start[b]; start[b] = acc; acc += c; }
+            std::vector<int32_t> order((size_t)acc);
+            for (int r = 0; r < n_rows; ++r) {
+                const int deg = rp[r + 1] - rp[r];
+                if (deg <= kLongThreshold) order[(size_t)start[(deg + 7) / 8]++] = r;
+            }
+            if (hipMalloc(&p->row_order, sizeof(int32_t) * order.size()) != hipSuccess ||
+                hipMemcpy(p->row_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                sgx_plan_destroy(p);
+                return SGX_ERR_HIP;
+            }
+            p->n_ordered = (int)order.size();
+        }
+    }
     *out = p;
     return SGX_OK;
 }
@@ -210,7 +252,11 @@ extern "C" void sgx_plan_destroy(sgx_plan *plan)
 {
     if (!plan) return;
     if (plan->long_row) (void)hipFree(plan->long_row);     // one blob, long_row is its base
+    if (plan->row_order) (void)hipFree(plan->row_order);
     delete plan;
 }
+
+extern "C" float sgx_plan_natural_utilization(const sgx_plan *plan) { return plan ? plan->natural_utilization : 1.0f; }
+extern "C" int sgx_plan_reordered(const sgx_plan *plan) { return plan && plan->row_order ? 1 : 0; }
 
 extern "C" int sgx_plan_long_rows(const sgx_plan *plan) { return plan ? plan->n_long : 0; }

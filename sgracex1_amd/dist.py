@@ -45,6 +45,30 @@ def slice_rows(rowptr, col, val, lo, hi):
     return (rowptr[lo:hi + 1] - rowptr[lo]).contiguous(), col[e0:e1].contiguous(), val[e0:e1].contiguous()
 
 
+def _host_staged(t, group):
+    """gloo moves host memory: device tensors are staged through the CPU when the job runs on gloo
+    (CPU tests, and rehearsing several ranks on one GPU); RCCL takes device tensors directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_into(out, inp, group=None):
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def all_to_all_rows(out, inp, out_splits, in_splits, group=None):
+    if _host_staged(inp, group) or (out.is_cuda and dist.get_backend(group) == "gloo"):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 @dataclass
 class HaloPlan:
     """Index structures of the halo exchange for one rank (all tensors on the compute device)."""
@@ -87,11 +111,11 @@ def build_halo_plan(col_global: torch.Tensor, bounds: List[int], rank: int, grou
     # tell every owner which of its rows we need
     counts_out = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
     counts_in = torch.empty_like(counts_out)
-    dist.all_to_all_single(counts_in, counts_out, group=group)
+    all_to_all_rows(counts_in, counts_out, None, None, group=group)
     send_counts = [int(c) for c in counts_in.tolist()]
     req_out = torch.cat(need) if sum(recv_counts) else col64.new_empty(0)
     req_in = col64.new_empty(sum(send_counts))
-    dist.all_to_all_single(req_in, req_out, output_split_sizes=send_counts, input_split_sizes=recv_counts, group=group)
+    all_to_all_rows(req_in, req_out, send_counts, recv_counts, group=group)
     return HaloPlan(bounds, rank, col_compact.to(torch.int32), (req_in - lo).contiguous(), send_counts, recv_counts,
                     hi - lo)
 
@@ -124,9 +148,16 @@ def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, gr
     if h_global is None:
         h_global = torch.empty((bounds[-1], P), dtype=h_local.dtype, device=h_local.device)
     if len(set(sizes)) == 1:
-        dist.all_gather_into_tensor(h_global, h_local.contiguous(), group=group)
+        all_gather_into(h_global, h_local.contiguous(), group=group)
     else:
-        dist.all_gather(list(h_global.split(sizes)), h_local.contiguous(), group=group)
+        # unequal blocks (nnz-balanced partition): gather blocks padded to the largest, then compact
+        big = max(sizes)
+        padded = h_local.new_zeros((big, P))
+        padded[:h_local.shape[0]] = h_local
+        stage = h_local.new_empty((world * big, P))
+        all_gather_into(stage, padded, group=group)
+        for g in range(world):
+            h_global[bounds[g]:bounds[g + 1]] = stage[g * big:g * big + sizes[g]]
     return backend.spmm(adj_local, h_global, relu)
 
 
@@ -138,6 +169,5 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
         table = torch.empty((plan.n_table, P), dtype=h_local.dtype, device=h_local.device)
     table[:plan.n_own] = h_local
     packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
-    dist.all_to_all_single(table[plan.n_own:], packed, output_split_sizes=plan.recv_counts,
-                           input_split_sizes=plan.send_counts, group=group)
+    all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
     return backend.spmm(adj_compact, table, relu)

@@ -1,0 +1,213 @@
+"""Host side of jupyter/molecule_gcn/Graph_Classification.ipynb (MOL), same class names,
+constructor and forward argument lists, with the FPGA offload replaced by the HIP kernels:
+
+    RPYNQ, FPYNQ                 MOL cell 16   (torch.autograd.Function)
+    Relu_pynq, GraphConvolution_pynq   MOL cell 17
+    GraphConvolution             MOL cell 15   (the plain torch layer)
+    GCN_PYNQ                     MOL cell 18
+
+Differences that are forced by the platform, not by choice:
+  * tensors live on the GPU; the eight `*_buffer` arguments of the forward calls are accepted
+    and ignored when they are None (the reference stages CSR arrays through those PYNQ buffers;
+    here the CSR arrays are handed to the kernel directly).  Passing real `pynq_shim` buffers
+    still works and takes the register-map / AP_START path.
+  * `adj` may be a dense tensor (as in the notebook, which builds a dense N x N matrix with
+    to_dense_adj), a torch sparse CSR tensor, or an `ops.Csr`.
+  * backward stays in torch on the device (the reference runs it in torch on the ARM CPU),
+    except the two `adj @ ...` products, which go through the aggregation kernel.  Like the
+    reference it multiplies by `adj`, not `adj^T` (exact for the symmetric graphs it is used on).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn import Linear
+from torch.nn.modules.module import Module
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .pyg_lite import global_mean_pool, to_dense_adj
+
+ACC_DTYPE = torch.float16          # MOL cell 11: every accelerator buffer is np.float16
+
+
+def as_csr(adj, dtype):
+    """Dense / torch-sparse / ops.Csr -> ops.Csr in `dtype` (MOL cell 18 `adj._to_sparse_csr()`)."""
+    if isinstance(adj, ops.Csr):
+        return adj.to(dtype)
+    if adj.layout == torch.sparse_csr:
+        return ops.Csr(adj.crow_indices().to(torch.int32).contiguous(), adj.col_indices().to(torch.int32).contiguous(),
+                       adj.values().to(dtype).contiguous(), adj.shape[1])
+    if adj.layout == torch.sparse_coo:
+        adj = adj.to_dense()
+    return ops.Csr.from_dense(adj, dtype)
+
+
+class RPYNQ(torch.autograd.Function):
+    """MOL cell 16: identity forward (the ReLU already ran inside the layer), backward zeroes the
+    gradient where the layer's output is exactly 0."""
+
+    @staticmethod
+    def forward(ctx, input):
+        ctx.save_for_backward(input)
+        return input.clone()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, = ctx.saved_tensors
+        grad_input = grad_output.clone()
+        if grad_input.is_cuda and input.dtype in (torch.float16, torch.float32) and \
+                grad_input.dtype in (torch.float16, torch.float32):
+            ops.relu_mask_backward_(input.contiguous(), grad_input)
+        else:
+            grad_input[input == 0] = 0
+        return grad_input
+
+
+class FPYNQ(torch.autograd.Function):
+    """MOL cell 16.  forward(ctx, my_ip, adj, input, weights) -> Tensor[N, P] in the accelerator's
+    element type; backward -> (None, None, grad_input, grad_weights) with
+    grad_W = input^T @ adj @ g and grad_x = adj @ g @ W^T."""
+
+    @staticmethod
+    def forward(ctx, my_ip, adj, input, weights):
+        rm = my_ip.register_map
+        dense = int(rm.gemm_mode)
+        A = as_csr(adj, ACC_DTYPE)
+        rm.N_adj, rm.M_adj = A.n_rows, A.n_rows                     # MOL cell 16: both = adj.shape[0]
+        rm.M_fea, rm.P_w = input.shape[1], weights.shape[1]
+        Wt = torch.transpose(weights, 0, 1).detach().to(ACC_DTYPE).contiguous()      # B_buffer <- W^T
+        if dense:
+            fea = input.detach().to(ACC_DTYPE).contiguous()
+        else:
+            fea = as_csr(input.detach(), ACC_DTYPE)
+        output_acc = my_ip.run_layer(A, fea, Wt)
+        ctx.adj = A
+        ctx.save_for_backward(input, weights, output_acc)
+        return output_acc
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weights, output = ctx.saved_tensors
+        A = ctx.adj
+        input = input.float()
+        if input.layout != torch.strided:
+            input = input.to_dense()
+        g = grad_output.float()
+        ag = ops.spmm(A.to(torch.float32), g.contiguous())          # adj @ g   (fp32, like the CPU path)
+        grad_weights = input.t() @ ag                               # input^T @ adj @ g
+        grad_input = ag @ weights.float().t()                       # adj @ g @ W^T
+        return None, None, grad_input, grad_weights
+
+
+class Relu_pynq(Module):
+    def __init__(self):
+        super(Relu_pynq, self).__init__()
+        self.fn = RPYNQ.apply
+
+    def forward(self, x):
+        return self.fn(x)
+
+
+class GraphConvolution(Module):
+    """MOL cell 15: `adj @ input @ weight` in plain torch (bias optional)."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super(GraphConvolution, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = Parameter(torch.FloatTensor(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, adj):
+        output = adj @ input @ self.weight
+        return output + self.bias if self.bias is not None else output
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class GraphConvolution_pynq(Module):
+    """MOL cell 17.  The bias parameter exists and is never added, as in the reference."""
+
+    def __init__(self, in_features, out_features, my_ip, bias=True):
+        super(GraphConvolution_pynq, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = Parameter(torch.FloatTensor(in_features, out_features))
+        self.fn = FPYNQ.apply
+        self.my_ip = my_ip
+        if bias:
+            self.bias = Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def run_kernel(self):
+        self.my_ip.register_map.CTRL.AP_START = 1
+        kernel_done = self.my_ip.register_map.CTRL.AP_DONE
+        while kernel_done == 0:
+            kernel_done = self.my_ip.register_map.CTRL.AP_DONE
+
+    def forward(self, acc, dense, relu, input, adj, rowPtr_fea_buffer=None, columnIndex_fea_buffer=None,
+                values_fea_buffer=None, rowPtr_adj_buffer=None, columnIndex_adj_buffer=None,
+                values_adj_buffer=None, B_buffer=None, D_buffer=None):
+        if acc == 1:
+            self.my_ip.register_map.relu = relu
+            self.my_ip.register_map.gemm_mode = dense
+            output = self.fn(self.my_ip, adj, input, self.weight)
+        else:
+            input = input.float()
+            if isinstance(adj, ops.Csr):
+                adj = torch.sparse_csr_tensor(adj.rowptr.long(), adj.col.long(), adj.val.float(),
+                                              size=(adj.n_rows, adj.n_cols))
+            output = adj @ input @ self.weight                       # the acc == 0 parity twin
+        return output
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class GCN_PYNQ(torch.nn.Module):
+    """MOL cell 18: conv1 (sparse X, ReLU in the kernel) -> Relu_pynq -> conv2 (dense X) ->
+    global_mean_pool -> dropout(0.5) -> Linear."""
+
+    def __init__(self, hidden_channels, num_node_features, num_classes, my_ip):
+        super(GCN_PYNQ, self).__init__()
+        torch.manual_seed(12345)
+        self.conv1 = GraphConvolution_pynq(num_node_features, hidden_channels, my_ip)
+        self.conv2 = GraphConvolution_pynq(hidden_channels, hidden_channels, my_ip)
+        self.reluh = Relu_pynq()
+        self.lin = Linear(hidden_channels, num_classes)
+
+    def forward(self, acc, x, edge_index, batch, rowPtr_fea_buffer=None, columnIndex_fea_buffer=None,
+                values_fea_buffer=None, rowPtr_adj_buffer=None, columnIndex_adj_buffer=None,
+                values_adj_buffer=None, B_buffer=None, D_buffer=None):
+        bufs = (rowPtr_fea_buffer, columnIndex_fea_buffer, values_fea_buffer, rowPtr_adj_buffer,
+                columnIndex_adj_buffer, values_adj_buffer, B_buffer, D_buffer)
+        adj = torch.squeeze(to_dense_adj(edge_index, num_nodes=x.shape[0]))
+        if acc == 1:
+            adj = ops.Csr.from_dense(adj, ACC_DTYPE)                 # pynq_adj = adj._to_sparse_csr()
+        dense, relu = 0, 1
+        x = self.conv1(acc, dense, relu, x, adj, *bufs)
+        x = x.relu() if acc == 0 else self.reluh(x)
+        dense, relu = 1, 0
+        x = self.conv2(acc, dense, relu, x, adj, *bufs)
+        x = x.float()
+        x = global_mean_pool(x, batch)
+        x = F.dropout(x, p=0.5, training=self.training)
+        return self.lin(x)

@@ -79,6 +79,14 @@ class Plan:
     def long_rows(self):
         return lib.sgx_plan_long_rows(self._h)
 
+    @property
+    def natural_utilization(self):
+        return lib.sgx_plan_natural_utilization(self._h)
+
+    @property
+    def reordered(self):
+        return bool(lib.sgx_plan_reordered(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

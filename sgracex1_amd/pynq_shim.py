@@ -1,0 +1,278 @@
+"""A `pynq`-shaped front end for the MI355X kernel, so that the reference's host code -- which
+drives its FPGA through `pynq.Overlay(...).mmult_top_0.register_map`, `pynq.allocate` buffers and
+the AP_START / AP_DONE handshake -- runs unchanged (jupyter/test/mmult-master.ipynb cells 2-38,
+jupyter/molecule_gcn/Graph_Classification.ipynb cells 11 and 16; demo/sgrace_lib/sgrace.py:13-16,
+:335-420, :1271).
+
+    from sgracex1_amd import pynq_shim; pynq_shim.install()     # makes `import pynq` resolve here
+    from pynq import Overlay, allocate
+
+What is mirrored:
+  * `allocate(shape, dtype)` -> a numpy array in host memory with `.physical_address` (an opaque
+    handle, unique per buffer, offsets allowed) and `.freebuffer()`;
+  * `Overlay(bitfile).mmult_top_0.register_map`: an attribute bag holding every register the
+    reference writes (names of K.cpp:3777-3861 and of the GAT bitstream's .hwh); unknown names are
+    accepted and stored, like writes to a real register file;
+  * `register_map.CTRL.AP_START = 1` runs one layer: the registers are decoded, the buffers behind
+    the `*_offset_1` addresses are copied to HBM, sgx_layer_forward runs on the current stream,
+    D (and E / S) are copied back into the host buffers, then `CTRL.AP_DONE` reads 1 once
+    (clear-on-read, as the HLS block's ap_done).
+The four per-thread aliases of each port (rowPtr_fea1..4 ...) collapse to the first, exactly as the
+reference passes the same address to all four.  Host buffers cost one PCIe round trip per layer;
+code that keeps its tensors on the GPU uses `IP.run_layer` (what the autograd Functions call).
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+
+_NP2TORCH = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32}
+
+_ADDR_STRIDE = 1 << 36          # fake "physical" address space: one 64 GiB window per buffer
+_buffers = {}                   # window index -> PynqBuffer
+_next_window = [1]
+
+
+class PynqBuffer(np.ndarray):
+    """numpy array with the two members of pynq's buffer the reference touches."""
+
+    def __new__(cls, shape, dtype):
+        obj = np.zeros(shape, dtype=dtype).view(cls)
+        win = _next_window[0]
+        _next_window[0] += 1
+        obj._window = win
+        _buffers[win] = obj
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._window = getattr(obj, "_window", None)
+
+    @property
+    def physical_address(self):
+        base = self
+        while isinstance(base.base, np.ndarray):
+            base = base.base
+        off = self.__array_interface__["data"][0] - base.__array_interface__["data"][0]
+        return self._window * _ADDR_STRIDE + off
+
+    @property
+    def device_address(self):
+        return self.physical_address
+
+    def freebuffer(self):
+        _buffers.pop(self._window, None)
+
+    close = freebuffer
+
+    def flush(self):
+        pass
+
+    def invalidate(self):
+        pass
+
+    sync_to_device = flush
+    sync_from_device = invalidate
+
+
+def allocate(shape, dtype=np.uint32, target=None, **kwargs):
+    return PynqBuffer(shape, np.dtype(dtype))
+
+
+def _resolve(addr):
+    """(flat host view starting at `addr`, owning buffer) for a fake physical address."""
+    addr = int(addr)
+    win, off = divmod(addr, _ADDR_STRIDE)
+    buf = _buffers.get(win)
+    if buf is None:
+        raise ValueError(f"register points at 0x{addr:x}, which is not inside a live allocate() buffer")
+    base = buf
+    while isinstance(base.base, np.ndarray):
+        base = base.base
+    flat = np.asarray(base).reshape(-1)
+    if off % flat.itemsize:
+        raise ValueError("buffer offset is not a multiple of the element size")
+    return flat[off // flat.itemsize:], flat.dtype
+
+
+class _Ctrl:
+    """CTRL register: AP_START (write 1 = run), AP_DONE (clear on read), AP_IDLE, AP_READY."""
+
+    def __init__(self, ip):
+        object.__setattr__(self, "_ip", ip)
+        object.__setattr__(self, "_done", 0)
+        object.__setattr__(self, "AUTO_RESTART", 0)
+
+    def __setattr__(self, name, value):
+        if name == "AP_START":
+            if int(value):
+                self._ip._start()
+                object.__setattr__(self, "_done", 1)
+        else:
+            object.__setattr__(self, name, value)
+
+    @property
+    def AP_START(self):
+        return 0
+
+    @property
+    def AP_DONE(self):
+        done = self._done
+        object.__setattr__(self, "_done", 0)
+        return done
+
+    @property
+    def AP_IDLE(self):
+        return 1
+
+    @property
+    def AP_READY(self):
+        return 0
+
+    def __repr__(self):
+        return f"Register(AP_START=0, AP_DONE={self._done}, AP_IDLE=1, AP_READY=0)"
+
+
+class RegisterMap:
+    """Attribute bag; every scalar the reference writes is kept as written."""
+
+    _DEFAULTS = dict(gemm_mode=0, relu=0, gat_mode=0, N_adj=0, M_adj=0, M_fea=0, P_w=0, bias_count=0,
+                     array_c_adjust=0, zero_point_lhs=0, zero_point_rhs=0, zero_point_dst=0, clamp_max=0,
+                     clamp_min=0, nnz_adj1=0, nnz_fea1=0)
+
+    def __init__(self, ip):
+        object.__setattr__(self, "_regs", dict(self._DEFAULTS))
+        object.__setattr__(self, "CTRL", _Ctrl(ip))
+
+    def __setattr__(self, name, value):
+        if name == "CTRL":
+            raise AttributeError("CTRL is a register with fields; write CTRL.AP_START")
+        if isinstance(value, (float, np.floating)) and float(value).is_integer():
+            value = int(value)          # the notebooks compute addresses with '/', e.g. MMN cell 31
+        self._regs[name] = value
+
+    def __getattr__(self, name):
+        try:
+            return object.__getattribute__(self, "_regs")[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __repr__(self):
+        body = ",\n  ".join(f"{k} = {v}" for k, v in self._regs.items())
+        return "RegisterMap {\n  CTRL = %r,\n  %s\n}" % (self.CTRL, body)
+
+
+class IP:
+    """`ol.mmult_top_0`: the register map plus the device-side fast path."""
+
+    def __init__(self, device=None, coo_adjacency=False):
+        self.device = torch.device("cuda" if device is None else device)
+        self.coo_adjacency = coo_adjacency      # the GAT bitstream is fed COO row indices (SG.py:1245)
+        self.alpha = 0.2
+        self.register_map = RegisterMap(self)
+
+    # -- fast path: everything already in HBM ------------------------------------------------
+    def run_layer(self, adj, fea, Wt, attention=None, want_edge_outputs=False, out=None):
+        """One layer with the flags currently in the register map (relu, gat_mode; gemm_mode is
+        implied by the type of `fea` and checked against the register)."""
+        from . import ops
+        rm = self.register_map
+        gemm_mode = 0 if isinstance(fea, ops.Csr) else 1
+        if int(rm.gemm_mode) != gemm_mode:
+            raise ValueError(f"register_map.gemm_mode={rm.gemm_mode} but the features are "
+                             f"{'CSR' if gemm_mode == 0 else 'dense'}")
+        rm.N_adj, rm.M_adj, rm.M_fea, rm.P_w = adj.n_rows, adj.n_cols, Wt.shape[1], Wt.shape[0]
+        gat = attention if int(rm.gat_mode) else None
+        return ops.layer_forward(adj, fea, Wt, relu=int(rm.relu), gat_attention=gat, alpha=self.alpha,
+                                 want_edge_outputs=want_edge_outputs, bias_count=int(rm.bias_count), out=out)
+
+    # -- compat path: host buffers behind fake physical addresses ------------------------------
+    def _start(self):
+        from . import ops
+        rm = self.register_map
+        N, M_adj, M_fea, P = int(rm.N_adj), int(rm.M_adj), int(rm.M_fea), int(rm.P_w)
+        if min(N, M_adj, M_fea, P) <= 0:
+            raise ValueError("N_adj, M_adj, M_fea and P_w must be set before AP_START")
+        dev = self.device
+
+        def view(reg, count, want=None):
+            flat, dt = _resolve(getattr(rm, reg))
+            if flat.size < count:
+                raise ValueError(f"{reg}: buffer holds {flat.size} elements, the layer needs {count}")
+            return flat[:count]
+
+        def up(a, dtype=None):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            return t if dtype is None else t.to(dtype)
+
+        B = view("B_offset_1", P * M_fea)
+        if B.dtype not in _NP2TORCH:
+            raise TypeError("B buffer must be float16 or float32")
+        tdt = _NP2TORCH[B.dtype]
+        Wt = up(B).reshape(P, M_fea)
+        if self.coo_adjacency:
+            nnz_a = int(rm.nnz_adj1)
+            rows = up(view("rowPtr_adj1_offset_1", nnz_a).astype(np.int32))
+            adj = ops.Csr.from_coo(rows, up(view("columnIndex_adj1_offset_1", nnz_a).astype(np.int32)),
+                                   up(view("values_adj1_offset_1", nnz_a), tdt), N, M_adj)
+        else:
+            rp = view("rowPtr_adj1_offset_1", N + 1).astype(np.int32)
+            nnz_a = int(rp[N])
+            adj = ops.Csr(up(rp), up(view("columnIndex_adj1_offset_1", nnz_a).astype(np.int32)),
+                          up(view("values_adj1_offset_1", nnz_a), tdt), M_adj)
+        if int(rm.gemm_mode) == 0:
+            if self.coo_adjacency:
+                nnz_f = int(rm.nnz_fea1)
+                fea = ops.Csr.from_coo(up(view("rowPtr_fea1_offset_1", nnz_f).astype(np.int32)),
+                                       up(view("columnIndex_fea1_offset_1", nnz_f).astype(np.int32)),
+                                       up(view("values_fea1_offset_1", nnz_f), tdt), M_adj, M_fea)
+            else:
+                rp = view("rowPtr_fea1_offset_1", M_adj + 1).astype(np.int32)
+                nnz_f = int(rp[M_adj])
+                fea = ops.Csr(up(rp), up(view("columnIndex_fea1_offset_1", nnz_f).astype(np.int32)),
+                              up(view("values_fea1_offset_1", nnz_f), tdt), M_fea)
+        else:
+            fea = up(view("values_fea1_offset_1", M_adj * M_fea), tdt).reshape(M_adj, M_fea)
+        att = None
+        if int(rm.gat_mode):
+            att = up(view("ate_m_offset_1", 2 * P), tdt)
+        want_es = bool(int(rm.gat_mode)) and "E1_offset_1" in rm._regs and "S1_offset_1" in rm._regs
+        res = ops.layer_forward(adj, fea, Wt, relu=int(rm.relu), gat_attention=att, alpha=self.alpha,
+                                want_edge_outputs=want_es, bias_count=int(rm.bias_count))
+        if int(rm.bias_count) > 0:
+            return                                   # K.cpp:3876-3889: nothing is written
+        out = res[0] if want_es else res
+        D = view("D1_offset_1", N * P)
+        D[:] = out.reshape(-1).to(tdt).cpu().numpy().astype(D.dtype, copy=False)
+        if want_es:
+            view("E1_offset_1", adj.nnz)[:] = res[1].cpu().numpy()
+            view("S1_offset_1", adj.nnz)[:] = res[2].cpu().numpy()
+        if "profiling_offset_1" in rm._regs:
+            try:
+                view("profiling_offset_1", 15)[:] = 0        # K.cpp:3948-3962: the FIFO taps read 0
+            except ValueError:
+                pass
+
+
+class Overlay:
+    """`Overlay("gnn_all.bit")`: the bitstream name only selects which IP flavour is mimicked."""
+
+    def __init__(self, bitfile="gnn_all.bit", download=True, device=None, **kwargs):
+        self.bitfile_name = bitfile
+        gat = "gat" in str(bitfile).lower()
+        self.mmult_top_0 = IP(device=device, coo_adjacency=gat)
+        self.ip_dict = {"mmult_top_0": {"type": "xilinx.com:hls:mmult_top:1.0", "driver": "sgracex1_amd.pynq_shim.IP"}}
+
+    def download(self):
+        pass
+
+
+def install():
+    """Register this module as `pynq` so the reference's `from pynq import Overlay, allocate` works."""
+    mod = types.ModuleType("pynq")
+    mod.Overlay, mod.allocate, mod.PynqBuffer = Overlay, allocate, PynqBuffer
+    mod.get_rails = lambda: {}
+    mod.DataRecorder = type("DataRecorder", (), {"__init__": lambda self, *a, **k: None})
+    mod.__doc__ = "pynq front end provided by sgracex1_amd.pynq_shim"
+    sys.modules["pynq"] = mod
+    return mod

@@ -1,0 +1,221 @@
+"""Host side of demo/sgrace_lib/sgrace.py (SG.py), same public names and signatures:
+
+    sym_norm2                 SG.py:18-51
+    RPYNQ                     SG.py:267-296
+    FPYNQ_GAT                 SG.py:298-1126   forward(ctx, my_ip, self, adj, nnz_adj, input, weights,
+                                               attention, out_features, dropout, relu)
+    Relu_SGRACE               SG.py:1142-1162
+    GATConv_SGRACE            SG.py:1164-1260  forward(compute_attention, dense, relu, input,
+                                               edge_index, norm, adj)
+    init_SGRACE               SG.py:1271
+
+`config.acc == 1` runs the layer on the GPU through the C ABI (GCN aggregate or single-head GAT
+edge softmax, selected by `compute_attention` -> register gat_mode); `config.acc == 0` is the
+reference's dense torch emulation (SG.py:563-681) kept as the parity twin.  The quantisation
+machinery of the SGRACE bitstream (SG.py:53-265, :570-616, :1645-1848) is not part of this path:
+`config.fake_quantization` must be 0.
+
+Backward mirrors SG.py:884-1126 (the `accb == 0` branch) on the edge list instead of dense
+N x N matrices: grad_input = P @ (g @ W^T), grad_weights = X^T @ (P @ g) with P = the attention
+matrix (GAT) or adj (GCN) -- like the reference, P and not P^T -- and for GAT the attention-vector
+gradient through softmax and LeakyReLU.
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn import LeakyReLU, init
+from torch.nn.modules.module import Module
+from torch.nn.parameter import Parameter
+
+from . import config, ops
+from .molecule_gcn import RPYNQ  # noqa: F401  (same Function in both reference files)
+from .pyg_lite import add_remaining_self_loops, sort_edge_index
+
+my_ip = None
+
+
+def _torch_dtype():
+    import numpy as np
+    return torch.float16 if np.dtype(config.float_type) == np.dtype(np.float16) else torch.float32
+
+
+def sym_norm2(edge_index, num_nodes, edge_weight=None, fill=0, dtype=None):
+    """SG.py:18-51: add the missing self loops with weight `fill`, sort by (row, col),
+    D^-1/2 A D^-1/2 with D = row sums."""
+    if edge_weight is None:
+        edge_weight = torch.ones((edge_index.size(1),), dtype=dtype, device=edge_index.device)
+    edge_index, edge_weight = add_remaining_self_loops(edge_index, edge_weight, fill, num_nodes)
+    edge_index, edge_weight = sort_edge_index(edge_index, edge_weight, num_nodes)
+    row, col = edge_index
+    deg = torch.zeros(num_nodes, dtype=edge_weight.dtype, device=edge_weight.device).index_add_(0, row, edge_weight)
+    deg_inv_sqrt = deg.pow(-0.5)
+    deg_inv_sqrt[deg_inv_sqrt == float('inf')] = 0
+    return edge_index, deg_inv_sqrt[row] * edge_weight * deg_inv_sqrt[col]
+
+
+def _edge_csr(adj, edge_index, norm, n, dtype):
+    """The CSR the kernel reads, from the (row-sorted) COO the reference ships (SG.py:1243-1247)."""
+    if isinstance(adj, ops.Csr):
+        return adj.to(dtype)
+    row = edge_index[0].to(torch.int32).contiguous()
+    return ops.Csr.from_coo(row, edge_index[1].to(torch.int32).contiguous(), norm.to(dtype).contiguous(), n, n)
+
+
+class FPYNQ_GAT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, my_ip, self, adj, nnz_adj, input, weights, attention, out_features, dropout, relu):
+        ctx.nheads, ctx.alpha, ctx.relu = self.nheads, self.alpha, relu
+        ctx.gat = int(config.compute_attention)
+        if config.fake_quantization:
+            raise NotImplementedError("the quantised SGRACE path is outside this package (set config.fake_quantization = 0)")
+        if config.acc == 1:
+            dt = _torch_dtype()
+            rm = my_ip.register_map
+            A = self._csr if isinstance(adj, torch.Tensor) else adj
+            A = A.to(dt)
+            Wt = weights.detach().t().to(dt).contiguous()
+            fea = input.detach()
+            if int(rm.gemm_mode) == 0:
+                fea = ops.Csr.from_dense(fea if fea.layout == torch.strided else fea.to_dense(), dt)
+            else:
+                fea = fea.to(dt).contiguous()
+            my_ip.alpha = self.alpha
+            if ctx.gat:
+                out, E, S = my_ip.run_layer(A, fea, Wt, attention=attention.detach().to(dt).reshape(-1).contiguous(),
+                                            want_edge_outputs=True)
+            else:
+                out, E, S = my_ip.run_layer(A, fea, Wt), None, None
+            ctx.csr = A
+            ctx.save_for_backward(input, weights, out, *([E, S] if ctx.gat else []))
+            return out.float()                                            # SG.py:543 `.float()`
+
+        # ---- no accelerator: the dense emulation of SG.py:563-681 --------------------------------
+        input = input.float()
+        Wh = torch.mm(input, weights)
+        adj_d = adj.to_dense()
+        Wh1 = torch.matmul(Wh, attention[:out_features, :])
+        Wh2 = torch.matmul(Wh, attention[out_features:, :])
+        e = self.leakyrelu(Wh1 + Wh2.T)
+        attention1 = torch.where(adj_d > 0, e, -9e15 * torch.ones_like(e))
+        attentions = F.softmax(attention1, dim=1)
+        if ctx.gat:
+            output_cpu = torch.matmul(attentions, Wh)
+        else:
+            output_cpu = torch.matmul(adj_d, Wh)
+        if relu == 1:
+            output_cpu = torch.where(output_cpu > 0, output_cpu, torch.zeros_like(output_cpu))
+        ctx.csr = None
+        ctx.save_for_backward(input, weights, output_cpu, e, attentions if ctx.gat else adj_d, adj_d)
+        return output_cpu
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        none = None
+        g = grad_output.float()
+        if ctx.csr is None:                                               # dense twin (SG.py:884-1126)
+            input, weights, output, e, P, adj_d = ctx.saved_tensors
+            Wh = input @ weights
+            if ctx.gat:
+                softmax_out = g @ Wh.t()
+                dx = P * softmax_out
+                sg = dx - P * dx.sum(dim=1, keepdim=True)
+                sg = torch.where(adj_d > 0, sg, torch.zeros_like(sg))
+                sg = ((e > 0) + ctx.alpha * (e <= 0)) * sg
+                grad_attention = torch.cat([Wh.t() @ sg.sum(dim=1), (sg @ Wh).sum(dim=0)]).unsqueeze(1)
+            else:
+                grad_attention = torch.zeros((2 * weights.shape[1], 1), device=g.device)
+            grad_input = P @ (g @ weights.t())
+            grad_weights = input.t() @ (P @ g)
+            return none, none, none, none, grad_input, grad_weights, grad_attention, none, none, none
+
+        saved = ctx.saved_tensors
+        input, weights, out = saved[0].float(), saved[1].float(), saved[2]
+        if input.layout != torch.strided:
+            input = input.to_dense()
+        A = ctx.csr
+        if ctx.gat:
+            E, S = saved[3], saved[4]
+            P = ops.Csr(A.rowptr, A.col, S.contiguous(), A.n_cols, A._plan)       # attention matrix, fp32 values
+            Wh = input @ weights
+            row = torch.repeat_interleave(torch.arange(A.n_rows, device=g.device),
+                                          (A.rowptr[1:] - A.rowptr[:-1]).long())
+            col = A.col.long()
+            d_alpha = (g[row] * Wh[col]).sum(dim=1)                               # (g @ Wh^T) on the edges
+            dx = S * d_alpha
+            rs = torch.zeros(A.n_rows, device=g.device).index_add_(0, row, dx)
+            sg = dx - S * rs[row]
+            sg = torch.where(A.val.float() > 0, sg, torch.zeros_like(sg))
+            sg = torch.where(E > 0, sg, ctx.alpha * sg)
+            g1 = torch.zeros(A.n_rows, device=g.device).index_add_(0, row, sg)    # row sums of sg
+            g2 = torch.zeros(A.n_cols, device=g.device).index_add_(0, col, sg)    # column sums of sg
+            grad_attention = torch.cat([Wh.t() @ g1, Wh.t() @ g2]).unsqueeze(1)
+        else:
+            P = A.to(torch.float32)
+            grad_attention = torch.zeros((2 * weights.shape[1], 1), device=g.device)
+        grad_input = ops.spmm(P, (g @ weights.t()).contiguous())
+        grad_weights = input.t() @ ops.spmm(P, g.contiguous())
+        return none, none, none, none, grad_input, grad_weights, grad_attention, none, none, none
+
+
+class Relu_SGRACE(Module):
+    def __init__(self):
+        super(Relu_SGRACE, self).__init__()
+        self.fn = RPYNQ.apply
+
+    def forward(self, x):
+        return self.fn(x)
+
+
+class GATConv_SGRACE(Module):
+    """GAT / GCN layer of the SGRACE library.  `nheads` only widens W (single head, SG.py:1176-1178);
+    the bias parameter exists and is never added, as in the reference."""
+
+    def __init__(self, in_features, out_features, nheads=1, bias=True, dropout=0.2, alpha=0.2, concat=False):
+        super(GATConv_SGRACE, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.alpha, self.dropout = alpha, dropout
+        self.weight = Parameter(torch.FloatTensor(in_features, out_features * nheads))
+        init.xavier_uniform_(self.weight.data, gain=1.414)
+        self.attention = Parameter(torch.empty(size=(2 * out_features * nheads, 1)))
+        init.xavier_uniform_(self.attention.data, gain=1.414)
+        self.leakyrelu = LeakyReLU(self.alpha)
+        self.nheads, self.concat = nheads, concat
+        self.fn = FPYNQ_GAT.apply
+        self.my_ip = my_ip if config.acc == 1 else None
+        self._csr = None
+        if bias:
+            self.bias = Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter('bias', None)
+
+    def run_kernel(self):
+        self.my_ip.register_map.CTRL.AP_START = 1
+        kernel_done = self.my_ip.register_map.CTRL.AP_DONE
+        while kernel_done == 0:
+            kernel_done = self.my_ip.register_map.CTRL.AP_DONE
+
+    def forward(self, compute_attention, dense, relu, input, edge_index, norm, adj):
+        nnz_adj = len(norm)
+        if config.acc == 1:
+            if self.my_ip is None:
+                self.my_ip = my_ip
+            if self.my_ip is None:
+                raise RuntimeError("call init_SGRACE() before the first forward (config.acc == 1)")
+            rm = self.my_ip.register_map
+            rm.relu, rm.gemm_mode, rm.gat_mode = relu, dense, compute_attention
+            rm.nnz_adj1 = nnz_adj
+            self._csr = _edge_csr(adj, edge_index, norm, input.shape[0], _torch_dtype())
+        return self.fn(self.my_ip, self, adj, nnz_adj, input, self.weight, self.attention, self.out_features,
+                       self.dropout, relu)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+def init_SGRACE(device=None):
+    """SG.py:1271: opens the overlay and publishes the IP handle the layers use."""
+    global my_ip
+    if config.acc == 1:
+        from .pynq_shim import Overlay
+        ol = Overlay("gat_all_unsigned.bit", device=device or config.device)
+        my_ip = ol.mmult_top_0
+    return my_ip

@@ -1,0 +1,68 @@
+"""The partitioned layer with the real HIP backend: two ranks share the one GPU of the box and
+exchange through gloo (staged through host memory) -- the code path of `bench.py --gpus N`, whose
+collective is RCCL on a multi-GPU node."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sgracex1_amd import dist as D, graphs, ops
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        n, f_in, p = 6000, 96, 64
+        A = graphs.uniform_graph(n, 60000, seed=7, device=dev)                # same graph on both ranks
+        g = torch.Generator(device=dev)
+        g.manual_seed(8)
+        X = torch.rand((n, f_in), generator=g, device=dev).half()
+        Wt = ((torch.rand((p, f_in), generator=g, device=dev) - 0.5) / 4).half()
+        want = ops.layer_forward(A, X, Wt, relu=True)
+        bounds = D.row_partition(n, world, A.rowptr)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci, va = D.slice_rows(A.rowptr, A.col, A.val, lo, hi)
+        backend = D.hip_backend()
+        d1 = D.layer_allgather(backend, ops.Csr(rp, ci, va, n), X[lo:hi].contiguous(), Wt, True, bounds)
+        assert torch.equal(d1, want[lo:hi])
+        plan = D.build_halo_plan(ci, bounds, rank)
+        d2 = D.layer_halo(backend, ops.Csr(rp, plan.col_compact, va, plan.n_table), X[lo:hi].contiguous(), Wt, True, plan)
+        assert torch.equal(d2, want[lo:hi])
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_rank():
+    port = 29700 + os.getpid() % 1000
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+        assert all(os.path.exists(os.path.join(tmp, f"ok{r}")) for r in range(2))
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py as the driver launches it for N > 1, on the small workload, 2 ranks on one GPU over gloo."""
+    env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--workload", "small"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["config"]["exchange"].startswith("RCCL all-gather")

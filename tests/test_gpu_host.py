@@ -1,0 +1,213 @@
+"""The host mirror of the reference interface on a real GPU: the notebook's register-map flow
+(mmult-master.ipynb cells 16-38) through the pynq-shaped shim, the autograd Functions and modules
+of molecule_gcn and of the SGRACE library against their own `acc == 0` torch twins."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _fixtures import GOLD, half_ulp_distance, known_answers, load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_notebook_register_map_flow_citeseer(oracle):
+    """mmult-master.ipynb, cell by cell: allocate, load text matrices, write the registers,
+    AP_START, poll AP_DONE, read D_buffer -- and compare row 0 with what the notebook recorded
+    from the FPGA (cell 37) and with the oracle."""
+    from sgracex1_amd import pynq_shim
+    pynq_shim.install()
+    from pynq import Overlay, allocate                                     # cell 2, 16
+    d = load("citeseer")
+    N_adj, M_fea, P_w = 3327, 3703, 16                                     # cell 6
+    NNZ_adj, NNZ_fea = 12431, 105165
+    ol = Overlay("gnn_all.bit")
+    my_ip = ol.mmult_top_0                                                 # cell 11
+    profiling_buffer = allocate(16, dtype=np.int64)
+    rowPtr_fea_buffer = allocate(N_adj + 1, dtype=np.int32)
+    columnIndex_fea_buffer = allocate(NNZ_fea, dtype=np.int32)
+    values_fea_buffer = allocate(200000, dtype=np.float16)
+    rowPtr_adj_buffer = allocate(N_adj + 1, dtype=np.int32)
+    columnIndex_adj_buffer = allocate(NNZ_adj, dtype=np.int32)
+    values_adj_buffer = allocate(NNZ_adj, dtype=np.float16)
+    B_buffer = allocate(shape=(P_w, M_fea), dtype=np.float16)
+    D_buffer = allocate(shape=(N_adj, P_w), dtype=np.float16)
+    w = d["w"].astype(np.float16)                                          # cell 18: genfromtxt(dtype=float16)
+    B_buffer[:] = w[:, :P_w].T
+    D_buffer[:] = 1                                                        # cell 21
+    rowPtr_adj_buffer[:] = d["adj_rowptr"]                                 # cell 25
+    columnIndex_adj_buffer[:] = d["adj_col"]
+    values_adj_buffer[:] = d["adj_val"].astype(np.float16)
+    rowPtr_fea_buffer[:] = d["fea_rowptr"]                                 # cell 26
+    columnIndex_fea_buffer[:] = d["fea_col"]
+    values_fea_buffer[0:NNZ_fea] = d["fea_val"].astype(np.float16)
+    rm = my_ip.register_map                                                # cell 31
+    rm.B_offset_1 = B_buffer.physical_address
+    rm.D1_offset_1 = D_buffer.physical_address
+    rm.D2_offset_1 = D_buffer.physical_address + P_w * N_adj / 1
+    for k in "1234":
+        setattr(rm, f"rowPtr_fea{k}_offset_1", rowPtr_fea_buffer.physical_address)
+        setattr(rm, f"columnIndex_fea{k}_offset_1", columnIndex_fea_buffer.physical_address)
+        setattr(rm, f"values_fea{k}_offset_1", values_fea_buffer.physical_address)
+        setattr(rm, f"rowPtr_adj{k}_offset_1", rowPtr_adj_buffer.physical_address)
+        setattr(rm, f"columnIndex_adj{k}_offset_1", columnIndex_adj_buffer.physical_address)
+        setattr(rm, f"values_adj{k}_offset_1", values_adj_buffer.physical_address)
+    rm.profiling_offset_1 = profiling_buffer.physical_address
+    rm.M_fea, rm.N_adj, rm.M_adj, rm.P_w = M_fea, N_adj, N_adj, P_w
+    rm.relu, rm.gemm_mode, rm.bias_count = 0, 0, 0
+
+    def run_kernel():                                                      # cell 32
+        my_ip.register_map.CTRL.AP_START = 1
+        kernel_done = my_ip.register_map.CTRL.AP_DONE
+        while kernel_done == 0:
+            kernel_done = my_ip.register_map.CTRL.AP_DONE
+
+    run_kernel()
+    result = np.zeros(shape=(N_adj, P_w), dtype=np.float16)                # cell 36
+    result[:] = D_buffer[:]
+    hw = np.array([float(t) for t in known_answers()["hw_row0_fp16_P16"]], dtype=np.float16)
+    # cell 37 is the FPGA's half-accumulated row; the fp32-accumulated row sits inside the stated band
+    np.testing.assert_allclose(result[0].astype(np.float32), hw.astype(np.float32), rtol=1e-2, atol=2e-3)
+    h = lambda a: oracle.to_half(np.asarray(a, np.float32)).astype(np.float32)
+    want = oracle.layer_f64(0, 0, (d["adj"][0], d["adj"][1], h(d["adj"][2])), (d["fea"][0], d["fea"][1], h(d["fea"][2])),
+                            h(np.ascontiguousarray(d["w"][:, :P_w].T)), h_round=2)
+    np.testing.assert_allclose(result.astype(np.float32), want, rtol=1e-2, atol=2e-3)
+    assert not profiling_buffer[:15].any()                                 # cells 39-40: all zero
+    # relu register and the dense mode through the same registers
+    rm.relu = 1
+    run_kernel()
+    assert np.array_equal(D_buffer, np.maximum(result, np.float16(0)))
+    # bias_count > 0: the kernel returns without touching D (K.cpp:3876-3889)
+    D_buffer[:] = 3
+    rm.bias_count = 2
+    run_kernel()
+    assert (D_buffer == 3).all()
+
+
+def _mutag_batch(device):
+    from sgracex1_amd import pyg_lite as G
+    raw = np.load(os.path.join(GOLD, "mutag_raw.npz"))
+    graphs = G.load_tu_raw(raw["A"], raw["graph_indicator"], raw["graph_labels"], raw["node_labels"])
+    return G.collate(graphs).to(device), graphs
+
+
+def test_fpynq_forward_backward_matches_torch_twin():
+    """FPYNQ (forward on the kernel, fp16) against `adj @ x @ W` autograd in fp32 on the same
+    symmetric graph: outputs within the fp16 band, gradients within 1e-2 relative."""
+    from sgracex1_amd import molecule_gcn as M, pynq_shim
+    from sgracex1_amd.pyg_lite import to_dense_adj
+    dev = torch.device("cuda")
+    batch, _ = _mutag_batch(dev)
+    adj = to_dense_adj(batch.edge_index, batch.num_nodes)[0]
+    ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
+    torch.manual_seed(0)
+    layer = M.GraphConvolution_pynq(7, 64, ip).to(dev)
+    x = batch.x.clone().requires_grad_(True)
+    out = layer(1, 0, 1, x, adj)                                           # acc, dense, relu
+    assert out.dtype == torch.float16 and out.shape == (3371, 64)
+    ref_x = batch.x.clone().requires_grad_(True)
+    ref = torch.relu(adj @ ref_x @ layer.weight)
+    np.testing.assert_allclose(out.float().detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-2, atol=2e-3)
+    assert ((out == 0) == (ref <= 0)).float().mean() > 0.999
+    g = torch.randn_like(ref)
+    # RPYNQ masks where the layer output is 0, exactly what relu's autograd does on the twin
+    y = M.Relu_pynq()(out)
+    y.backward(g.half())
+    gw_dev = layer.weight.grad.clone()
+    layer.weight.grad = None
+    ref.backward(g)
+    scale = layer.weight.grad.abs().max()
+    assert (gw_dev - layer.weight.grad).abs().max() / scale < 1e-2
+    assert (x.grad - ref_x.grad).abs().max() / ref_x.grad.abs().max() < 1e-2
+    # dense mode (layer 2 of the notebook) and the acc == 0 twin of the module itself
+    layer2 = M.GraphConvolution_pynq(64, 64, ip).to(dev)
+    o2 = layer2(1, 1, 0, out.detach(), adj)
+    t2 = layer2(0, 1, 0, out.detach(), adj)
+    np.testing.assert_allclose(o2.detach().float().cpu().numpy(), t2.detach().cpu().numpy(), rtol=1e-2, atol=4e-3)
+
+
+def test_gcn_pynq_model_acc_vs_cpu_twin():
+    from sgracex1_amd import molecule_gcn as M, pynq_shim
+    dev = torch.device("cuda")
+    batch, _ = _mutag_batch(dev)
+    ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
+    model = M.GCN_PYNQ(64, 7, 2, ip).to(dev).eval()
+    with torch.no_grad():
+        a = model(1, batch.x, batch.edge_index, batch.batch)
+        b = model(0, batch.x, batch.edge_index, batch.batch)
+    assert a.shape == (188, 2)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-2, atol=5e-3)
+
+
+@pytest.mark.parametrize("compute_attention", [0, 1])
+def test_gatconv_sgrace_acc_vs_dense_emulation(compute_attention):
+    """GATConv_SGRACE with config.acc = 1 (kernels) against config.acc = 0 (the reference's dense
+    torch emulation), forward and all three gradients, on cora."""
+    from sgracex1_amd import config, sgrace
+    dev = torch.device("cuda")
+    d = load("cora")
+    n = d["N"]
+    rp, ci, _ = d["adj"]
+    row = np.repeat(np.arange(n), np.diff(rp))
+    keep = row != ci
+    ei = torch.as_tensor(np.stack([row[keep], ci[keep]]), dtype=torch.int64, device=dev)
+    edge_index, norm = sgrace.sym_norm2(ei, n, fill=1, dtype=torch.float32)
+    adj = torch.sparse_coo_tensor(edge_index, norm, (n, n))
+    X = torch.zeros((n, d["M_fea"]), device=dev)
+    frow = np.repeat(np.arange(n), np.diff(d["fea"][0]))
+    X[torch.as_tensor(frow, device=dev), torch.as_tensor(d["fea"][1].astype(np.int64), device=dev)] = 1.0
+    X = X[:, :256].contiguous()                                         # keep the dense twin small
+    outs = {}
+    for acc in (1, 0):
+        config.acc, config.compute_attention, config.fake_quantization = acc, compute_attention, 0
+        config.device = "cuda"
+        sgrace.init_SGRACE()
+        torch.manual_seed(5)
+        layer = sgrace.GATConv_SGRACE(256, 16, 1, dropout=0.1, alpha=0.2).to(dev)
+        x = X.clone().requires_grad_(True)
+        out = layer(compute_attention, 1, 1, x, edge_index, norm, adj)       # dense=1, relu=1
+        out = sgrace.Relu_SGRACE()(out)
+        torch.manual_seed(6)
+        out.backward(torch.randn_like(out))
+        outs[acc] = (out.detach(), x.grad.clone(), layer.weight.grad.clone(), layer.attention.grad.clone())
+    config.acc = 1
+    for k, (a, b) in enumerate(zip(outs[1], outs[0])):
+        if k == 3 and not compute_attention:
+            assert not a.any() and not b.any()
+            continue
+        err = (a - b).abs().max() / (b.abs().max() + 1e-12)
+        assert err < 2e-3, (k, float(err))
+
+
+def test_mutag_training_reaches_reference_accuracy():
+    """molecule_gcn end to end (MOL cells 6-20): 188-graph batch, hidden 64, Adam lr 0.01, fp16
+    kernels in forward, torch backward; the notebook reports test accuracy 0.62 -> 0.76 at epoch
+    34 on graphs [50:100] of its shuffle.  The shuffle depends on the torch version, so the bar
+    here is: the training loss falls and the same 50-graph slice reaches >= 0.72 within 60 epochs."""
+    from sgracex1_amd import molecule_gcn as M, pyg_lite as G, pynq_shim
+    dev = torch.device("cuda")
+    raw = np.load(os.path.join(GOLD, "mutag_raw.npz"))
+    graphs = G.load_tu_raw(raw["A"], raw["graph_indicator"], raw["graph_labels"], raw["node_labels"])
+    torch.manual_seed(12345)
+    perm = torch.randperm(len(graphs)).tolist()
+    graphs = [graphs[i] for i in perm]
+    train, test = G.collate(graphs[:2000]).to(dev), G.collate(graphs[50:100]).to(dev)
+    ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
+    model = M.GCN_PYNQ(64, 7, 2, ip).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    crit = torch.nn.CrossEntropyLoss()
+    losses, best = [], 0.0
+    for epoch in range(60):
+        model.train()
+        opt.zero_grad()
+        loss = crit(model(1, train.x, train.edge_index, train.batch), train.y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        model.eval()
+        with torch.no_grad():
+            pred = model(1, test.x, test.edge_index, test.batch).argmax(dim=1)
+        best = max(best, float((pred == test.y).float().mean()))
+    assert losses[-1] < losses[0]
+    assert best >= 0.72, best

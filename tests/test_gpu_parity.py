@@ -306,3 +306,28 @@ def test_from_dense_matches_torch_csr(sgx):
     A = sgx.Csr.from_dense(dense, torch.float16)
     sp = dense.to_sparse_csr()
     assert torch.equal(A.rowptr.long(), sp.crow_indices()) and torch.equal(A.col.long(), sp.col_indices())
+
+
+def test_spmm_table_beyond_4gib(sgx):
+    """A gathered table of 4 GiB or more (the all-gathered H of an 8-GPU run) takes the 64-bit
+    pointer path instead of 32-bit buffer offsets; rows on both sides of the 4 GiB line."""
+    n_cols, P = (1 << 25) + 4096, 64                                # 4.0005 GiB of fp16
+    H = torch.empty((n_cols, P), dtype=torch.float16, device="cuda")
+    H.copy_(((torch.arange(n_cols, device="cuda") % 251).to(torch.float16) / 16).unsqueeze(1).expand(n_cols, P))
+    H[:, 1] = 1.0
+    rng = np.random.default_rng(5)
+    n_rows = 4099
+    deg = rng.integers(0, 12, n_rows)
+    rp = np.zeros(n_rows + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, n_cols, rp[-1]).astype(np.int32)
+    ci[::3] = n_cols - 1 - (ci[::3] % 4096)                          # plenty of rows past 2^32 bytes
+    va = (rng.integers(1, 5, rp[-1]) / 4).astype(np.float32)
+    A = sgx.Csr(_dev(rp), _dev(ci), _dev(va, torch.float16), n_cols)
+    got = sgx.spmm(A, H, relu=False, use_plan=False).float()
+    rows = torch.as_tensor(np.repeat(np.arange(n_rows), deg), device="cuda")
+    want = torch.zeros((n_rows, P), device="cuda").index_add_(0, rows, H[torch.as_tensor(ci, device="cuda").long()].float()
+                                                            * torch.as_tensor(va, device="cuda").unsqueeze(1))
+    assert torch.allclose(got, want, rtol=2e-3, atol=2e-3)
+    assert torch.allclose(got[:, 1], torch.as_tensor(np.add.reduceat(np.append(va, 0), rp[:-1]) * (deg > 0),
+                                                      device="cuda", dtype=torch.float32), rtol=2e-3, atol=2e-3)

@@ -1,0 +1,113 @@
+"""Host-side logic that needs no GPU: the pynq-shaped register map and buffers, the graph
+helpers around the hot path (TU loader, batching, to_dense_adj, pooling, sym_norm2), the row
+partition of the multi-GPU path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _fixtures import GOLD, load
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from sgracex1_amd import build
+    build.build()
+
+
+def test_allocate_and_physical_addresses():
+    from sgracex1_amd import pynq_shim as P
+    a = P.allocate(100, dtype=np.int32)
+    b = P.allocate(shape=(4, 8), dtype=np.float16)
+    assert a.shape == (100,) and a.dtype == np.int32 and not a.any()
+    assert b.shape == (4, 8) and b.dtype == np.float16
+    assert a.physical_address != b.physical_address
+    flat, dt = P._resolve(a.physical_address)
+    flat[3] = 7
+    assert a[3] == 7 and dt == np.int32
+    # an address inside a buffer (the notebooks add byte offsets for D2..D4, MMN cell 31)
+    flat2, _ = P._resolve(b.physical_address + 2 * 8 * 2)
+    flat2[0] = 1.5
+    assert b[2, 0] == np.float16(1.5)
+    assert b[1:].physical_address == b.physical_address + 16
+    a.freebuffer()
+    with pytest.raises(ValueError):
+        P._resolve(a.physical_address)
+
+
+def test_register_map_semantics():
+    from sgracex1_amd import pynq_shim as P
+    ol = P.Overlay("gnn_all.bit", device="cpu")
+    ip = ol.mmult_top_0
+    rm = ip.register_map
+    rm.N_adj, rm.relu, rm.gemm_mode = 3327, 1, 0
+    rm.D2_offset_1 = 1000 + 16 * 3327 / 1            # float arithmetic, as MMN cell 31 writes it
+    assert rm.N_adj == 3327 and rm.relu == 1 and rm.D2_offset_1 == 1000 + 16 * 3327
+    rm.some_new_register = 5                          # unknown names are stored like any register
+    assert rm.some_new_register == 5
+    assert rm.CTRL.AP_DONE == 0 and rm.CTRL.AP_IDLE == 1
+    with pytest.raises(AttributeError):
+        rm.never_written
+    with pytest.raises(ValueError):                   # AP_START without dimensions
+        rm2 = P.Overlay("gnn_all.bit", device="cpu").mmult_top_0.register_map
+        rm2.CTRL.AP_START = 1
+    assert not P.Overlay("gnn_all.bit", device="cpu").mmult_top_0.coo_adjacency
+    assert P.Overlay("gat_all_unsigned.bit", device="cpu").mmult_top_0.coo_adjacency
+    mod = P.install()
+    import pynq
+    assert pynq is mod and pynq.Overlay is P.Overlay and pynq.allocate is P.allocate
+    del sys.modules["pynq"]
+
+
+def test_mutag_loader_and_batching():
+    from sgracex1_amd import pyg_lite as G
+    raw = np.load(os.path.join(GOLD, "mutag_raw.npz"))
+    graphs = G.load_tu_raw(raw["A"], raw["graph_indicator"], raw["graph_labels"], raw["node_labels"])
+    assert len(graphs) == 188 and sum(g.num_nodes for g in graphs) == 3371
+    assert sum(g.edge_index.shape[1] for g in graphs) == 7442
+    # first graph of the dataset, as printed in MOL cell 4: 17 nodes, 38 edges, 7 features
+    assert graphs[0].num_nodes == 17 and graphs[0].edge_index.shape[1] == 38 and graphs[0].x.shape[1] == 7
+    assert sorted(set(int(g.y) for g in graphs)) == [0, 1]
+    assert sum(int(g.y) for g in graphs) == 125                        # 125 positive / 63 negative
+    for g in graphs[:20]:
+        assert (g.x.sum(dim=1) == 1).all() and int(g.edge_index.max()) < g.num_nodes
+        d = G.to_dense_adj(g.edge_index, g.num_nodes)[0]
+        assert torch.equal(d, d.t()) and not torch.diagonal(d).any()     # undirected, no self loops
+    b = G.collate(graphs)
+    assert b.num_nodes == 3371 and b.edge_index.shape == (2, 7442) and b.num_graphs == 188   # MOL cell 10 output
+    pooled = G.global_mean_pool(b.x, b.batch)
+    assert pooled.shape == (188, 7) and torch.allclose(pooled.sum(dim=1), torch.ones(188))
+    loader = G.DataLoader(graphs[50:100], batch_size=256)
+    assert len(list(loader)) == 1
+
+
+def test_sym_norm2_reproduces_the_reference_cora_values():
+    """cora_adj.txt holds D^-1/2 (A + I) D^-1/2; rebuilding it from the bare structure with
+    sym_norm2(fill=1) must give the stored values (text precision).  (citeseer_adj.txt was
+    normalised before its duplicate edges were merged, so 4.6 % of its values cannot be rebuilt
+    from the structure alone.)"""
+    from sgracex1_amd.sgrace import sym_norm2
+    d = load("cora")
+    rp, ci, va = d["adj"]
+    n = d["N"]
+    row = np.repeat(np.arange(n), np.diff(rp))
+    keep = row != ci
+    ei = torch.as_tensor(np.stack([row[keep], ci[keep]]), dtype=torch.int64)
+    ei2, norm = sym_norm2(ei, n, fill=1, dtype=torch.float32)
+    assert ei2.shape[1] == len(ci)
+    assert np.array_equal(ei2[0].numpy(), row) and np.array_equal(ei2[1].numpy(), ci)   # sorted by (row, col)
+    np.testing.assert_allclose(norm.numpy(), va, rtol=2e-6, atol=1e-7)
+
+
+def test_row_partition_and_slices():
+    from sgracex1_amd import dist as D
+    assert D.row_partition(10, 4) == [0, 2, 4, 6, 10]                 # remainder to the last (K.cpp:3522)
+    rp = torch.tensor([0, 10, 10, 11, 20, 21, 40], dtype=torch.int32)
+    b = D.row_partition(6, 2, rp)
+    assert b[0] == 0 and b[-1] == 6 and 0 < b[1] < 6
+    col = torch.arange(40, dtype=torch.int32)
+    val = torch.ones(40)
+    r, c, v = D.slice_rows(rp, col, val, 2, 5)
+    assert r.tolist() == [0, 1, 10, 11] and c.tolist() == list(range(10, 21)) and v.numel() == 11
