@@ -157,7 +157,7 @@ size_t sgx_spmm_scratch_bytes(const sgx_plan *plan, int n_feat);
 /* X.W with dense X = loop_fea / compute1 in gemm_mode 1 (K.cpp:2932, :2605, :847-865),
  * on the matrix cores:  H[r][0:P] = sum_k X[r][k] * Wt[p][k].
  * X [n_rows][ldx], Wt [P][ldw] (= B), H [n_rows][ldh]; columns P..ldh-1 of H are zeroed. */
-int sgx_xw_dense(int dtype, int acc_mode, int n_rows, int M_fea, int P,
+int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P,
                  const void *X, int64_t ldx, const void *Wt, int64_t ldw,
                  void *H, int64_t ldh, void *stream);
 

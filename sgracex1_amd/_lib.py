@@ -79,7 +79,7 @@ def _load():
     lib.sgx_spmm_csr.restype = c_int
     lib.sgx_spmm_scratch_bytes.argtypes = [vp, c_int]
     lib.sgx_spmm_scratch_bytes.restype = sz
-    lib.sgx_xw_dense.argtypes = [c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp]
+    lib.sgx_xw_dense.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp]
     lib.sgx_xw_dense.restype = c_int
     lib.sgx_xw_sparse.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_i64, vp, c_i64,
                                   vp, vp, sz, vp]

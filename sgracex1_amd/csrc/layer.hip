@@ -88,7 +88,7 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         rc = sgx_xw_sparse(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
                            d->columnIndex_fea, d->values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s);
     } else {
-        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->M_adj, d->M_fea, d->P_w, d->values_fea, d->M_fea, d->B, d->M_fea,
+        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->values_fea, d->M_fea, d->B, d->M_fea,
                           H, ldh, s);
     }
     if (rc != SGX_OK) return rc;

@@ -280,6 +280,11 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     if (n_rows == 0) return SGX_OK;
     if (!rowPtr || !D) return SGX_ERR_NULL;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    if (acc_mode == SGX_ACC_REF_HALF) {
+        if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
+        if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
+        return sgx_refhalf_csr(spmm_block, relu, n_rows, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, stream);
+    }
     if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
     const size_t es = sgx_elem_size(dtype);

@@ -184,15 +184,21 @@ int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, 
 
 }  // namespace
 
-extern "C" int sgx_xw_dense(int dtype, int acc_mode, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
+extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                             const void *Wt, int64_t ldw, void *H, int64_t ldh, void *stream)
 {
     if (n_rows < 0 || M_fea < 1 || P < 1 || ldx < M_fea || ldw < M_fea || ldh < P) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
     if (!X || !Wt || !H) return SGX_ERR_NULL;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
-    if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (acc_mode == SGX_ACC_REF_HALF) {
+        // the reference's sequential half arithmetic (refhalf.hip)
+        if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
+        if (ldh > P) SGX_HIP_CHECK(hipMemsetAsync(H, 0, (size_t)n_rows * ldh * sizeof(f16), s));
+        return sgx_refhalf_dense(spmm_block, n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, s);
+    }
+    if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     const size_t es = sgx_elem_size(dtype);
     const int xa = ((uintptr_t)X % 16 == 0) && ((ldx * es) % 16 == 0);
     const int wa = ((uintptr_t)Wt % 16 == 0) && ((ldw * es) % 16 == 0);

@@ -199,9 +199,12 @@ class GCN_PYNQ(torch.nn.Module):
                 values_adj_buffer=None, B_buffer=None, D_buffer=None):
         bufs = (rowPtr_fea_buffer, columnIndex_fea_buffer, values_fea_buffer, rowPtr_adj_buffer,
                 columnIndex_adj_buffer, values_adj_buffer, B_buffer, D_buffer)
-        adj = torch.squeeze(to_dense_adj(edge_index, num_nodes=x.shape[0]))
         if acc == 1:
-            adj = ops.Csr.from_dense(adj, ACC_DTYPE)                 # pynq_adj = adj._to_sparse_csr()
+            # pynq_adj = to_dense_adj(edge_index)._to_sparse_csr() of the notebook, built from the
+            # edge list directly (same CSR, no dense N x N intermediate)
+            adj = ops.csr_from_edge_index(edge_index, x.shape[0], dtype=ACC_DTYPE)
+        else:
+            adj = torch.squeeze(to_dense_adj(edge_index, num_nodes=x.shape[0]))
         dense, relu = 0, 1
         x = self.conv1(acc, dense, relu, x, adj, *bufs)
         x = x.relu() if acc == 0 else self.reluh(x)

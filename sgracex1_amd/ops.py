@@ -142,7 +142,23 @@ class Csr:
         return Csr(rowptr, col.to(torch.int32).contiguous(), val.contiguous(), n_cols)
 
 
-def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True):
+def csr_from_edge_index(edge_index, n_rows, n_cols=None, values=None, dtype=torch.float16):
+    """[2, E] edge list (any order, duplicates add up) -> Csr, without the dense N x N detour of
+    `to_dense_adj(...)._to_sparse_csr()` (MOL cell 18): sort by (row, col), merge duplicates,
+    row pointer by sgx_coo_to_csr.  Gives the same CSR as the dense route."""
+    _dev(edge_index, "edge_index")
+    n_cols = n_rows if n_cols is None else n_cols
+    key = edge_index[0].to(torch.int64) * n_cols + edge_index[1].to(torch.int64)
+    w = torch.ones(key.numel(), dtype=torch.float32, device=key.device) if values is None else values.float()
+    ukey, inv = torch.unique(key, return_inverse=True)
+    val = torch.zeros(ukey.numel(), dtype=torch.float32, device=key.device).index_add_(0, inv, w)
+    row = torch.div(ukey, n_cols, rounding_mode="floor")
+    col = ukey - row * n_cols
+    keep = val != 0                                     # a dense matrix cannot hold explicit zeros either
+    return Csr.from_coo(row[keep].to(torch.int32), col[keep].to(torch.int32), val[keep].to(dtype), n_rows, n_cols)
+
+
+def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_ACC_F32, spmm_block=1):
     """D = act(A @ H[:, :n_feat]) -- the aggregation stage alone (sgx_spmm_csr)."""
     _dev2d(H, "H")
     code = dtype_code(H.dtype)
@@ -154,14 +170,14 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True):
     plan = adj.plan if use_plan else None
     sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
     scratch = _workspace(H.device, sbytes) if sbytes else None
-    check(lib.sgx_spmm_csr(code, SGX_ACC_F32, 1, int(bool(relu)), adj.n_rows, H.shape[0], n_feat,
+    check(lib.sgx_spmm_csr(code, acc_mode, spmm_block, int(bool(relu)), adj.n_rows, H.shape[0], n_feat,
                            _ptr(adj.rowptr), _ptr(adj.col), _ptr(adj.val), _ptr(H), H.stride(0),
                            _ptr(out), out.stride(0), plan.handle if plan is not None else None,
                            _ptr(scratch), sbytes, _stream()), "sgx_spmm_csr")
     return out
 
 
-def xw_dense(X, Wt, ldh=None):
+def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
     """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M]."""
     _dev2d(X, "X")
     _dev2d(Wt, "Wt")
@@ -170,7 +186,7 @@ def xw_dense(X, Wt, ldh=None):
     per16 = 8 if code == SGX_F16 else 4
     ldh = (P + per16 - 1) // per16 * per16 if ldh is None else ldh
     H = torch.empty((X.shape[0], ldh), dtype=X.dtype, device=X.device)
-    check(lib.sgx_xw_dense(code, SGX_ACC_F32, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0),
+    check(lib.sgx_xw_dense(code, acc_mode, spmm_block, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0),
                            _ptr(H), ldh, _stream()), "sgx_xw_dense")
     return H[:, :P]
 

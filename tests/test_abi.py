@@ -83,7 +83,7 @@ def test_argument_checks_need_no_gpu(L):
     assert need >= 10 * 8 * 2 and need % 256 == 0
     assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 0, None, None, None, None, 8, None, 8, None, None, 0, None) == -2
     assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 8, None, None, None, None, 8, None, 8, None, None, 0, None) == -1
-    assert L.lib.sgx_xw_dense(0, 0, 4, 0, 8, None, 8, None, 8, None, 8, None) == -2
+    assert L.lib.sgx_xw_dense(0, 0, 1, 4, 0, 8, None, 8, None, 8, None, 8, None) == -2
     assert L.lib.sgx_transpose(0, 4, 4, None, 4, None, 4, None) == -1
 
 

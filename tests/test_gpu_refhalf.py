@@ -1,0 +1,81 @@
+"""SGX_ACC_REF_HALF: the device reproduces the reference's HALF-build arithmetic bit for bit --
+checked against the oracle's model on the reference's own matrices for every SPMM_BLOCK, both
+feature modes, with and without ReLU, and against the csim log itself."""
+import numpy as np
+import pytest
+import torch
+
+from _fixtures import known_answers, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+def _csr(ops, csr, n_cols):
+    rp, ci, va = csr
+    return ops.Csr(_dev(rp.astype(np.int32)), _dev(ci.astype(np.int32)), _dev(va.astype(np.float32), torch.float16), n_cols)
+
+
+@pytest.mark.parametrize("name", ["mol", "cora", "citeseer", "test", "test2"])
+@pytest.mark.parametrize("spmm_block", [1, 2, 4, 8])
+def test_layer_bit_exact_sparse_features(oracle, name, spmm_block):
+    from sgracex1_amd import ops
+    d = load(name)
+    A, X = _csr(ops, d["adj"], d["N"]), _csr(ops, d["fea"], d["M_fea"])
+    Wt = _dev(d["Wt"], torch.float16)
+    for relu in (0, 1):
+        want = oracle.layer_refhalf(0, relu, d["adj"], d["fea"], d["Wt"], spmm_block=spmm_block)
+        got = ops.layer_forward(A, X, Wt, relu=relu, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block)
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("spmm_block", [1, 3, 4])
+def test_layer_bit_exact_dense_features(oracle, spmm_block):
+    """gemm_mode 1: zeros take part in the lane rotation (K.cpp:849-863), so this is a different
+    summation order from the sparse stream -- layer 2 of cora (dense 64 -> 7) and mol (7 -> 64)."""
+    from sgracex1_amd import ops
+    import os
+    from _fixtures import GOLD
+    d = load("cora")
+    w2 = np.load(os.path.join(GOLD, "cora.npz"))["w2"].astype(np.float32)
+    h1 = oracle.layer_refhalf(0, 1, d["adj"], d["fea"], d["Wt"], spmm_block=spmm_block)
+    want = oracle.layer_refhalf(1, 0, d["adj"], h1, np.ascontiguousarray(w2.T), spmm_block=spmm_block)
+    A = _csr(ops, d["adj"], d["N"])
+    got = ops.layer_forward(A, _dev(h1), _dev(np.ascontiguousarray(w2.T), torch.float16), relu=0,
+                            acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    m = load("mol")
+    want = oracle.layer_refhalf(1, 1, m["adj"], m["fea_dense"], m["Wt"], spmm_block=spmm_block)
+    got = ops.layer_forward(_csr(ops, m["adj"], m["N"]), _dev(m["fea_dense"], torch.float16), _dev(m["Wt"], torch.float16),
+                            relu=1, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_csim_log_from_the_device():
+    """The device in reference arithmetic (SPMM_BLOCK 4) prints the csim log: 40 of 42 values to the
+    digit, the other two one half-ulp away -- the same score as the CPU model."""
+    from sgracex1_amd import ops
+    d = load("citeseer")
+    ka = known_answers()["csim_log"]
+    got = ops.layer_forward(_csr(ops, d["adj"], d["N"]), _csr(ops, d["fea"], d["M_fea"]), _dev(d["Wt"], torch.float16),
+                            relu=0, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=4).cpu().numpy()
+    exact = sum("%g" % float(got[int(r), j]) == t for r in ("0", "31") for j, t in enumerate(ka[r]))
+    assert exact >= 40
+
+
+def test_stage_entry_points_in_reference_arithmetic(oracle):
+    from sgracex1_amd import ops
+    d = load("cora")
+    A = _csr(ops, d["adj"], d["N"])
+    rng = np.random.default_rng(0)
+    H = oracle.to_half(rng.standard_normal((d["N"], 24)).astype(np.float32))
+    got = ops.spmm(A, _dev(H), relu=True, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=4)
+    eye = np.eye(24, dtype=np.float32)
+    want = oracle.layer_refhalf(1, 1, d["adj"], H, eye, spmm_block=4)       # X.I is exact: isolates the A.H stage
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    with pytest.raises(RuntimeError):                                          # fp32 has no reference-half form
+        ops.spmm(A.to(torch.float32), _dev(H).float(), acc_mode=ops.SGX_ACC_REF_HALF)

@@ -39,6 +39,21 @@ def test_degree_ordered_schedule_is_bit_identical(dtype, P):
     assert not ordered[torch.as_tensor(np.diff(rp) == 0, device="cuda")].any()
 
 
+def test_csr_from_edge_index_equals_dense_route():
+    """Graph prep on the device: edge list -> CSR must equal to_dense_adj(...)._to_sparse_csr()."""
+    from sgracex1_amd import ops
+    from sgracex1_amd.pyg_lite import to_dense_adj
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    n = 700
+    ei = torch.randint(0, n, (2, 5000), generator=g, device="cuda")
+    ei = torch.cat([ei, ei[:, :300]], dim=1)                       # duplicates add up, as to_dense_adj does
+    a = ops.csr_from_edge_index(ei, n, dtype=torch.float32)
+    b = ops.Csr.from_dense(to_dense_adj(ei, n)[0], torch.float32)
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.col, b.col) and torch.equal(a.val, b.val)
+    a.validate()
+
+
 def test_uniform_graph_keeps_natural_order():
     from sgracex1_amd import graphs
     A = graphs.uniform_graph(1 << 14, 400_000, seed=1)
