@@ -11,11 +11,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Elem;
 template <> struct Elem<f16> {
     static constexpr int kVec = 8;       // elements per 16-byte gather
+    typedef u32x4 vec16_u __attribute__((aligned(2)));   // 16 bytes at element alignment
     static __device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
     static __device__ __forceinline__ f16 from_f32(float v) { return (f16)v; }   // v_cvt_f16_f32: RNE
 };
 template <> struct Elem<float> {
     static constexpr int kVec = 4;
+    typedef u32x4 vec16_u __attribute__((aligned(4)));
     static __device__ __forceinline__ float to_f32(float v) { return v; }
     static __device__ __forceinline__ float from_f32(float v) { return v; }
 };

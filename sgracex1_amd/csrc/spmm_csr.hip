@@ -81,8 +81,11 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
         // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
         out[i] = (!relu || v > (T)0) ? v : (T)0;
     }
-    if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
-        *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+    (void)vec_store;
+    if (VEC > 1 && col0 + VEC <= n_feat) {
+        // one 16-byte store even when the row of D is only element-aligned (P_w = 41, 47 ...):
+        // gfx950 global stores need element alignment only
+        *reinterpret_cast<typename Elem<T>::vec16_u *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
     } else {
 #pragma unroll
         for (int i = 0; i < VEC; ++i)

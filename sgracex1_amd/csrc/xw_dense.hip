@@ -23,12 +23,19 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// 8 consecutive K elements of one row, zero beyond k_end; vector load when the row is 16-byte aligned
+// Rows of X need not be 16-byte aligned (M_fea = 602 or 100 gives 4- / 8-byte aligned rows): gfx950
+// global loads only need element alignment, so the fragment is still ONE dwordx4 load through an
+// under-aligned vector type.
+typedef f16x8 f16x8_u __attribute__((aligned(2)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
+// 8 consecutive K elements of one row, zero beyond k_end
 __device__ __forceinline__ f16x8 load_k8(const f16 *__restrict__ row, int k, int k_end, bool row_ok, bool aligned)
 {
+    (void)aligned;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!row_ok) return v;
-    if (aligned && k + 8 <= k_end) return *reinterpret_cast<const f16x8 *>(row + k);
+    if (k + 8 <= k_end) return *reinterpret_cast<const f16x8_u *>(row + k);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         if (k + j < k_end) v[j] = row[k + j];
@@ -37,9 +44,10 @@ __device__ __forceinline__ f16x8 load_k8(const f16 *__restrict__ row, int k, int
 
 __device__ __forceinline__ f32x4 load_k4(const float *__restrict__ row, int k, int k_end, bool row_ok, bool aligned)
 {
+    (void)aligned;
     f32x4 v = {0, 0, 0, 0};
     if (!row_ok) return v;
-    if (aligned && k + 4 <= k_end) return *reinterpret_cast<const f32x4 *>(row + k);
+    if (k + 4 <= k_end) return *reinterpret_cast<const f32x4_u *>(row + k);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (k + j < k_end) v[j] = row[k + j];

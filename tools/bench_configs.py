@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Times the five BASELINE.json configurations (synthetic graphs of the stated shapes where the
+dataset is not in the container) on one GPU and prints one JSON line per configuration:
+per-stage times from hipEvents, edges/s, algorithmic GB/s of the aggregation stage.
+
+    python tools/bench_configs.py [--only c1,c3] [--iters 20]
+
+c1  molecule_gcn: the 188-graph MUTAG batch (3371 nodes, 7442 edges), 7 -> 64 -> 64, sparse X then dense X
+c2  Cora: the reference's cora_{adj,feat,weights}.txt, 1433 -> 64 (sparse X, ReLU) -> 7 (dense X)
+c3  Reddit shape: N 232,965, 114.6 M edges (uniform synthetic), dense X 602 -> 128 (ReLU) -> 41
+c4  ogbn-products shape: N 2,449,029, 123.7 M edges, dense X 100 -> 256 (ReLU) -> 47   (one GPU's view)
+c5  ogbn-arxiv shape GAT: N 169,343, 2.33 M edges + self loops, 128 -> 8 x 32 = 256 wide single softmax
+    (the reference's `nheads` only widens W, SG.py:1176-1178), relu = 1
+Small configurations (c1, c2) are launch-bound, so they are also timed replayed from a hipGraph.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sgracex1_amd import graphs, ops  # noqa: E402
+from sgracex1_amd.hipevents import Event  # noqa: E402
+
+dev = torch.device("cuda")
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    b, e = Event(), Event()
+    b.record(s)
+    for _ in range(iters):
+        fn()
+    e.record(s)
+    return b.elapsed_ms(e) / iters
+
+
+def graphed(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return timed(g.replay, iters)
+
+
+def rand_w(p, m, gen):
+    return ((torch.rand((p, m), generator=gen, device=dev) * 2 - 1) / p ** 0.5).half()
+
+
+def report(name, A, stages, extra):
+    rec = {"config": name, "nodes": A.n_rows, "edges": A.nnz}
+    rec.update(stages)
+    rec.update(extra)
+    print(json.dumps(rec), flush=True)
+
+
+def gcn_two_layer(name, A, X, W1t, W2t, iters, small=False):
+    hid, out = W1t.shape[0], W2t.shape[0]
+    D1 = torch.empty((A.n_rows, hid), dtype=torch.float16, device=dev)
+    D2 = torch.empty((A.n_rows, out), dtype=torch.float16, device=dev)
+    A.plan
+    if isinstance(X, ops.Csr):
+        X.plan
+
+    def fwd():
+        ops.layer_forward(A, X, W1t, relu=True, out=D1)
+        ops.layer_forward(A, D1, W2t, relu=False, out=D2)
+
+    t_fwd = timed(fwd, iters)
+    H1 = torch.empty((A.n_cols, hid), dtype=torch.float16, device=dev).normal_()
+    H2 = torch.empty((A.n_cols, max(8, (out + 7) // 8 * 8)), dtype=torch.float16, device=dev).normal_()
+    t_agg1 = timed(lambda: ops.spmm(A, H1, relu=True, out=D1), iters)
+    t_agg2 = timed(lambda: ops.spmm(A, H2, relu=False, n_feat=out, out=D2), iters)
+    if isinstance(X, ops.Csr):
+        Wrm = ops.transpose(W1t)
+        t_xw1 = timed(lambda: ops.spmm(X, Wrm, relu=False, out=D1), iters)
+    else:
+        t_xw1 = timed(lambda: ops.xw_dense(X, W1t), iters)
+    t_xw2 = timed(lambda: ops.xw_dense(D1, W2t), iters)
+    b_alg1 = A.nnz * (6 + hid * 2) + (A.n_rows + 1) * 4 + A.n_rows * hid * 2
+    extra = {"f_in": W1t.shape[1], "hidden": hid, "out": out,
+             "layer1": "sparse X" if isinstance(X, ops.Csr) else "dense X",
+             "edges_per_s_2layer": 2 * A.nnz / (t_fwd * 1e-3),
+             "agg1_algorithmic_GBps": b_alg1 / (t_agg1 * 1e-3) / 1e9,
+             "agg1_frac_of_8TBps": b_alg1 / (t_agg1 * 1e-3) / 8e12,
+             "plan": {"long_rows": A.plan.long_rows, "reordered": A.plan.reordered,
+                      "natural_utilization": round(A.plan.natural_utilization, 3)}}
+    stages = {"ms_forward_2layer": t_fwd, "ms_xw1": t_xw1, "ms_agg1": t_agg1, "ms_xw2": t_xw2, "ms_agg2": t_agg2}
+    if small:
+        stages["ms_forward_2layer_hipgraph"] = graphed(fwd, iters)
+    report(name, A, stages, extra)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="c1,c2,c3,c4,c5")
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    want = set(args.only.split(","))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+
+    if "c1" in want:
+        from _fixtures import GOLD
+        from sgracex1_amd import pyg_lite as G
+        raw = np.load(os.path.join(GOLD, "mutag_raw.npz"))
+        b = G.collate(G.load_tu_raw(raw["A"], raw["graph_indicator"], raw["graph_labels"], raw["node_labels"])).to(dev)
+        A = ops.csr_from_edge_index(b.edge_index, b.num_nodes)
+        X = ops.Csr.from_dense(b.x, torch.float16)
+        gcn_two_layer("c1 molecule_gcn MUTAG batch", A, X, rand_w(64, 7, gen), rand_w(64, 64, gen), 200, small=True)
+
+    if "c2" in want:
+        from _fixtures import GOLD, load
+        d = load("cora")
+        w2 = np.load(os.path.join(GOLD, "cora.npz"))["w2"].astype(np.float32)
+        A = graphs.csr_from_numpy(*d["adj"], d["N"])
+        X = graphs.csr_from_numpy(*d["fea"], d["M_fea"])
+        gcn_two_layer("c2 Cora (reference matrices)", A, X, torch.as_tensor(d["Wt"], device=dev).half(),
+                      torch.as_tensor(np.ascontiguousarray(w2.T), device=dev).half(), 200, small=True)
+
+    if "c3" in want:
+        n = 232_965
+        A = graphs.uniform_graph(n, 114_600_000, seed=3)
+        X = torch.rand((n, 602), generator=gen, device=dev).half()
+        gcn_two_layer("c3 Reddit shape", A, X, rand_w(128, 602, gen), rand_w(41, 128, gen), args.iters)
+        del A, X
+
+    if "c4" in want:
+        n = 2_449_029
+        A = graphs.uniform_graph(n, 123_700_000, seed=4)
+        X = torch.rand((n, 100), generator=gen, device=dev).half()
+        gcn_two_layer("c4 ogbn-products shape (1 GPU)", A, X, rand_w(256, 100, gen), rand_w(47, 256, gen), args.iters)
+        del A, X
+
+    if "c5" in want:
+        n, P = 169_343, 256
+        A = graphs.uniform_graph(n, 2_330_000, seed=5)
+        X = torch.rand((n, 128), generator=gen, device=dev).half()
+        Wt = rand_w(P, 128, gen)
+        att = ((torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.3).half()
+        D = torch.empty((n, P), dtype=torch.float16, device=dev)
+        A.plan
+        t_layer = timed(lambda: ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, out=D), 100)
+        Wh = ops.xw_dense(X, Wt)
+        t_gat = timed(lambda: ops.gat_aggregate(A, Wh, att, relu=True), 100)
+        t_gcn = timed(lambda: ops.spmm(A, Wh, relu=True, out=D), 100)
+        b_alg = A.nnz * (6 + 8 + P * 2) + (n + 1) * 4 + n * P * 2
+        report("c5 ogbn-arxiv shape GAT", A,
+               {"ms_layer": t_layer, "ms_gat_aggregate": t_gat, "ms_gcn_aggregate_same_shape": t_gcn},
+               {"f_in": 128, "width": P, "heads": "8 x 32 as one 256-wide single-softmax head (reference semantics)",
+                "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9})
+
+
+if __name__ == "__main__":
+    main()
