@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgx.so")
+# SGX_LIB_PATH selects another build of the same library (tools/sweep_spmm.py compares variants)
+LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_HERE, "csrc", "libsgx.so")
 
 SGX_F16, SGX_F32 = 0, 1
 SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1

@@ -56,7 +56,8 @@ extern "C" int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows
                              const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
 {
     // C[r][:] = sum_k Xval[k] * W[Xcol[k]][:]  (K.cpp:2009-2061): the aggregation kernel with the
-    // weight matrix as the gathered table (it fits L2: M_fea x P elements)
+    // weight matrix as the gathered table (it fits L2: M_fea x P elements).  (An LDS-resident weight
+    // tile, the literal form of the reference's B_accel, was built and measured slower: DESIGN.md 4.)
     return sgx_spmm_launch(dtype, acc_mode, spmm_block, /*relu*/0, n_rows, M_fea, P, rowPtr, columnIndex, values,
                            W_rowmajor, ldw, H, ldh, plan, scratch, scratch_bytes, (hipStream_t)stream);
 }

@@ -87,3 +87,28 @@ template <> struct GatherPtr<float, 1> {
         acc[0] = __builtin_fmaf(a, *reinterpret_cast<const float *>(p), acc[0]);
     }
 };
+
+// Broadcast of lane t of every LPR-lane group.  Groups of 2 or 4 lanes sit inside a quad, where DPP
+// quad_perm moves data inside the VALU (no LDS crossbar trip, no address register); wider groups
+// use ds_bpermute through __shfl.
+template <int LPR, int TT> struct GroupBcast {
+    static __device__ __forceinline__ int run(int x) { return __shfl(x, TT, LPR); }
+};
+template <int TT> struct GroupBcast<1, TT> {
+    static __device__ __forceinline__ int run(int x) { return x; }
+};
+template <int TT> struct GroupBcast<4, TT> {
+    static __device__ __forceinline__ int run(int x) {
+        return __builtin_amdgcn_update_dpp(0, x, TT | (TT << 2) | (TT << 4) | (TT << 6), 0xF, 0xF, false);
+    }
+};
+template <int TT> struct GroupBcast<2, TT> {
+    static __device__ __forceinline__ int run(int x) {
+        return __builtin_amdgcn_update_dpp(0, x, TT | (TT << 2) | ((2 + TT) << 4) | ((2 + TT) << 6), 0xF, 0xF, false);
+    }
+};
+template <int LPR, int TT> __device__ __forceinline__ int group_bcast(int x) { return GroupBcast<LPR, TT>::run(x); }
+template <int LPR, int TT> __device__ __forceinline__ float group_bcast(float x)
+{
+    return __builtin_bit_cast(float, GroupBcast<LPR, TT>::run(__builtin_bit_cast(int, x)));
+}

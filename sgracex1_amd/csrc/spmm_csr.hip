@@ -17,6 +17,17 @@
 //   * products and sums in fp32, one rounding to the storage type; ReLU fused into the store.
 #include "sgx_device.h"
 
+// Tuning knobs of the sblock kernel (defaults = the measured best, tools/sweep_spmm.py):
+#ifndef SGX_SPMM_MINWAVES
+#define SGX_SPMM_MINWAVES 1          // 2nd __launch_bounds__ argument: min wavefronts per SIMD
+#endif
+#ifndef SGX_SPMM_NT_STORE
+#define SGX_SPMM_NT_STORE 0          // non-temporal stores of D
+#endif
+#ifndef SGX_SPMM_BLOCKS_PER_CU
+#define SGX_SPMM_BLOCKS_PER_CU 512   // grid cap (2.18 vs 2.21 ms at 64 on S-100M); rows beyond it are grid-strided
+#endif
+
 namespace {
 
 // Sum of  values[e] * H[columnIndex[e]][col0 : col0+VEC]  over e in [e0, e1) stepping `stride`
@@ -85,7 +96,12 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
     if (VEC > 1 && col0 + VEC <= n_feat) {
         // one 16-byte store even when the row of D is only element-aligned (P_w = 41, 47 ...):
         // gfx950 global stores need element alignment only
+#if SGX_SPMM_NT_STORE
+        __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(out),
+                                    reinterpret_cast<typename Elem<T>::vec16_u *>(drow + col0));
+#else
         *reinterpret_cast<typename Elem<T>::vec16_u *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
@@ -97,7 +113,7 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 // sblock path: one group of LPR lanes per row, 64/LPR rows per wavefront.
 // ---------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPR, bool BIG>
-__global__ __launch_bounds__(kBlock) void spmm_sblock_kernel(
+__global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
     T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store,
@@ -212,7 +228,7 @@ int grid_for_rows(int64_t n_rows, int rows_per_wave)
 {
     const int64_t rows_per_block = (int64_t)rows_per_wave * (kBlock / 64);
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
-    const int64_t cap = 256 * 64;            // 64 blocks per CU, grid-stride beyond
+    const int64_t cap = 256 * SGX_SPMM_BLOCKS_PER_CU;      // grid-stride beyond
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
