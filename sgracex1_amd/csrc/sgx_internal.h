@@ -28,6 +28,7 @@ static inline int sgx_next_pow2(int x) { int p = 1; while (p < x) p <<= 1; retur
 // and the partial rows of one long row are added in task order (bitwise reproducible).
 struct sgx_plan {
     int n_rows;
+    int64_t nnz;
     int long_threshold;
     int chunk;
     int n_long;        // number of long rows

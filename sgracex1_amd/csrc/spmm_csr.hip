@@ -24,22 +24,31 @@
 #ifndef SGX_SPMM_NT_STORE
 #define SGX_SPMM_NT_STORE 0          // non-temporal stores of D
 #endif
+#include <stdlib.h>
+
 #ifndef SGX_SPMM_BLOCKS_PER_CU
 #define SGX_SPMM_BLOCKS_PER_CU 512   // grid cap (2.18 vs 2.21 ms at 64 on S-100M); rows beyond it are grid-strided
 #endif
 
 namespace {
 
-// Sum of  values[e] * H[columnIndex[e]][col0 : col0+VEC]  over e in [e0, e1) stepping `stride`
-// edges between this group's LPR-edge pieces.  `col_off` = byte offset of this lane's columns
-// inside a row of H, or kOOB when the lane has no valid column.
+constexpr double kShortRowDegree = 5.0;      // choose_cpl: mean degree below which lane groups are halved
+
+// Sum of  values[e] * H[columnIndex[e]][this lane's columns]  over e in [e0, e1) stepping `stride`
+// edges between this group's LPR-edge pieces.  A lane owns CPL chunks of VEC consecutive columns
+// (CPL x 16 bytes of the row); chunk_off[j] = byte offset of chunk j inside a row of H, or kOOB when
+// that chunk lies beyond n_feat.
+//   LPR x CPL x 16 bytes = one row of H.  CPL = 1 spends all lanes of a group on the row (8 edges per
+//   step at F = 64 fp16); CPL = 2 / 4 halves / quarters the group, so a wavefront keeps 2x / 4x as
+//   many rows in flight and wastes fewer gather slots on short rows -- chosen from the matrix's mean
+//   degree (sgx_plan).  Gathers in flight per lane stay at 8 either way.
 // BIG = the table is 4 GiB or larger: buffer offsets are 32 bit, so the gathers become 64-bit
 // global loads under a per-edge predicate (the all-gathered H of an 8-GPU run crosses this size).
-template <typename T, int VEC, int LPR, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int stride, int sub,
                                                  const int32_t *__restrict__ col, const T *__restrict__ val,
                                                  __amdgpu_buffer_rsrc_t rsrc, const T *__restrict__ table,
-                                                 unsigned ld_bytes, unsigned col_off)
+                                                 unsigned ld_bytes, const unsigned *chunk_off)
 {
     int c_next = 0;
     T a_next = (T)0;
@@ -59,7 +68,8 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
             a_next = __builtin_nontemporal_load(val + nidx);
         }
         const int n = e1 - base;                                // valid edges in this piece (>= 1)
-        constexpr int UNR = LPR < 8 ? LPR : 8;                  // gathers kept in flight per lane
+        constexpr int kInFlight = 8 / CPL;                      // edges whose gathers are issued together
+        constexpr int UNR = LPR < kInFlight ? LPR : kInFlight;
 #pragma unroll 1
         for (int t0 = 0; t0 < LPR; t0 += UNR) {
             if (t0 >= n) break;
@@ -68,13 +78,16 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
                 const int t = t0 + u;
                 const int cc = __shfl(c, t, LPR);
                 const float aa = __shfl(a, t, LPR);
-                const bool valid = t < n && col_off != kOOB;
-                if constexpr (!BIG) {
-                    Gather<T, VEC>::run(acc, aa, rsrc, valid ? (unsigned)cc * ld_bytes + col_off : kOOB);
-                } else {
-                    if (valid)
-                        GatherPtr<T, VEC>::run(acc, aa, reinterpret_cast<const char *>(table) +
-                                                            (size_t)(unsigned)cc * ld_bytes + col_off);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const bool valid = t < n && chunk_off[j] != kOOB;
+                    if constexpr (!BIG) {
+                        Gather<T, VEC>::run(acc + j * VEC, aa, rsrc, valid ? (unsigned)cc * ld_bytes + chunk_off[j] : kOOB);
+                    } else {
+                        if (valid)
+                            GatherPtr<T, VEC>::run(acc + j * VEC, aa, reinterpret_cast<const char *>(table) +
+                                                                          (size_t)(unsigned)cc * ld_bytes + chunk_off[j]);
+                    }
                 }
             }
         }
@@ -112,7 +125,7 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 // ---------------------------------------------------------------------------------------
 // sblock path: one group of LPR lanes per row, 64/LPR rows per wavefront.
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
@@ -120,7 +133,8 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
     const int32_t *__restrict__ row_order)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
-    constexpr int TILE = LPR * VEC;               // columns covered per pass
+    constexpr int LANE_COLS = CPL * VEC;          // columns per lane
+    constexpr int TILE = LPR * LANE_COLS;         // columns covered per pass
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -143,13 +157,21 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
         }
         if (!live) e1 = e0;
         for (int c0 = 0; c0 < n_feat; c0 += TILE) {
-            const int col0 = c0 + sub * VEC;
-            const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
-            float acc[VEC];
+            const int col0 = c0 + sub * LANE_COLS;
+            unsigned chunk_off[CPL];
+            float acc[LANE_COLS];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-            accumulate_edges<T, VEC, LPR, BIG>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, col_off);
-            if (live && col0 < n_feat) store_row<T, VEC>(D + r * ldd, col0, n_feat, acc, relu, vec_store != 0);
+            for (int j = 0; j < CPL; ++j)
+                chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
+#pragma unroll
+            for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
+            accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, chunk_off);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    if (col0 + j * VEC < n_feat)
+                        store_row<T, VEC>(D + r * ldd, col0 + j * VEC, n_feat, acc + j * VEC, relu, vec_store != 0);
+            }
         }
     }
 }
@@ -157,13 +179,14 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
 // ---------------------------------------------------------------------------------------
 // split path: one wavefront per (long row, edge chunk); fp32 partial rows.
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock) void spmm_split_kernel(
     int n_tasks, int n_feat, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
     const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes,
     unsigned ld_bytes, float *__restrict__ partial, int ldp)
 {
-    constexpr int TILE = LPR * VEC;
+    constexpr int LANE_COLS = CPL * VEC;
+    constexpr int TILE = LPR * LANE_COLS;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
@@ -173,19 +196,22 @@ __global__ __launch_bounds__(kBlock) void spmm_split_kernel(
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
     const int e0 = task_e0[task], e1 = task_e1[task];
     for (int c0 = 0; c0 < n_feat; c0 += TILE) {
-        const int col0 = c0 + sub * VEC;
-        const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
-        float acc[VEC];
+        const int col0 = c0 + sub * LANE_COLS;
+        unsigned chunk_off[CPL];
+        float acc[LANE_COLS];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-        accumulate_edges<T, VEC, LPR, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes, col_off);
+        for (int j = 0; j < CPL; ++j)
+            chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
+#pragma unroll
+        for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
+        accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes, chunk_off);
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+            for (int i = 0; i < LANE_COLS; ++i) acc[i] += __shfl_xor(acc[i], off);
         if (grp == 0) {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i)
+            for (int i = 0; i < LANE_COLS; ++i)
                 if (col0 + i < n_feat) partial[(int64_t)task * ldp + col0 + i] = acc[i];
         }
     }
@@ -234,23 +260,23 @@ int grid_for_rows(int64_t n_rows, int rows_per_wave)
     return (int)blocks;
 }
 
-template <typename T, int VEC, int LPR, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG>
 int launch_one_impl(const LaunchArgs &a)
 {
     const int long_thr = (a.plan && a.plan->n_long > 0) ? a.plan->long_threshold : 0;
     const int32_t *order = a.plan ? a.plan->row_order : nullptr;
     const int n_work = order ? a.plan->n_ordered : a.n_rows;
     if (n_work > 0) {
-        hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR, BIG>), dim3(grid_for_rows(n_work, 64 / LPR)),
+        hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR, CPL, BIG>), dim3(grid_for_rows(n_work, 64 / LPR)),
                            dim3(kBlock), 0, a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val,
                            (const T *)a.H, a.h_bytes, a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order);
         SGX_LAUNCH_CHECK();
     }
     if (long_thr > 0) {
         const sgx_plan *p = a.plan;
-        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR, BIG>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0, a.stream,
-                           p->n_tasks, a.n_feat, p->task_e0, p->task_e1, a.col, (const T *)a.val, (const T *)a.H,
-                           a.h_bytes, a.ld_bytes, a.partial, a.ldp);
+        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR, CPL, BIG>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0,
+                           a.stream, p->n_tasks, a.n_feat, p->task_e0, p->task_e1, a.col, (const T *)a.val,
+                           (const T *)a.H, a.h_bytes, a.ld_bytes, a.partial, a.ldp);
         SGX_LAUNCH_CHECK();
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((spmm_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)),
@@ -261,24 +287,45 @@ int launch_one_impl(const LaunchArgs &a)
     return SGX_OK;
 }
 
-template <typename T, int VEC, int LPR>
-int launch_one(const LaunchArgs &a)
+// slots = LPR * CPL = 16-byte chunks per row (power of two); cpl in {1, 2, 4}, cpl <= slots.
+// Tables of 4 GiB and more always run with CPL = 1.
+template <typename T, int VEC, int SLOTS>
+int launch_slots(const LaunchArgs &a, int cpl)
 {
-    return a.big ? launch_one_impl<T, VEC, LPR, true>(a) : launch_one_impl<T, VEC, LPR, false>(a);
+    if (a.big) return launch_one_impl<T, VEC, SLOTS, 1, true>(a);
+    if constexpr (VEC > 1 && SLOTS >= 4) {
+        if (cpl == 4) return launch_one_impl<T, VEC, SLOTS / 4, 4, false>(a);
+    }
+    if constexpr (VEC > 1 && SLOTS >= 2) {
+        if (cpl >= 2) return launch_one_impl<T, VEC, SLOTS / 2, 2, false>(a);
+    }
+    return launch_one_impl<T, VEC, SLOTS, 1, false>(a);
 }
 
 template <typename T, int VEC>
-int launch_lpr(const LaunchArgs &a, int lpr)
+int launch_lpr(const LaunchArgs &a, int slots, int cpl)
 {
-    switch (lpr) {
-    case 1: return launch_one<T, VEC, 1>(a);
-    case 2: return launch_one<T, VEC, 2>(a);
-    case 4: return launch_one<T, VEC, 4>(a);
-    case 8: return launch_one<T, VEC, 8>(a);
-    case 16: return launch_one<T, VEC, 16>(a);
-    case 32: return launch_one<T, VEC, 32>(a);
-    default: return launch_one<T, VEC, 64>(a);
+    switch (slots) {
+    case 1: return launch_slots<T, VEC, 1>(a, cpl);
+    case 2: return launch_slots<T, VEC, 2>(a, cpl);
+    case 4: return launch_slots<T, VEC, 4>(a, cpl);
+    case 8: return launch_slots<T, VEC, 8>(a, cpl);
+    case 16: return launch_slots<T, VEC, 16>(a, cpl);
+    case 32: return launch_slots<T, VEC, 32>(a, cpl);
+    default: return launch_slots<T, VEC, 64>(a, cpl);
     }
+}
+
+// Lanes per row from the mean degree.  Measured on 4 M-row uniform graphs at F = 64 fp16
+// (tools/cpl_probe.py): halving the lane group (CPL = 2) wins only below ~5 edges per row
+// (0.34 vs 0.47 ms at 2 edges/row, 0.48 vs 0.55 ms at 4) and loses above (1.23 vs 1.13 ms at 13,
+// 2.52 vs 2.18 ms at 25; sparse X.W 0.98 vs 0.86 ms); CPL = 4 never wins.
+int choose_cpl(const sgx_plan *plan, int slots)
+{
+    if (const char *f = getenv("SGX_SPMM_CPL")) return atoi(f);          // tuning override
+    if (!plan || plan->n_rows <= 0 || slots < 2) return 1;
+    const double avg = (double)plan->nnz / (double)plan->n_rows;
+    return avg < kShortRowDegree ? 2 : 1;
 }
 
 }  // namespace
@@ -326,13 +373,14 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     const bool vec_gather = ((uintptr_t)H % 16 == 0) && ((ldh * es) % 16 == 0);
     a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
     if (vec_gather) {
-        const int lpr = sgx_next_pow2((n_feat + per16 - 1) / per16);
-        return dtype == SGX_F16 ? launch_lpr<f16, 8>(a, lpr > 64 ? 64 : lpr)
-                                : launch_lpr<float, 4>(a, lpr > 64 ? 64 : lpr);
+        int slots = sgx_next_pow2((n_feat + per16 - 1) / per16);
+        if (slots > 64) slots = 64;
+        const int cpl = choose_cpl(plan, slots);
+        return dtype == SGX_F16 ? launch_lpr<f16, 8>(a, slots, cpl) : launch_lpr<float, 4>(a, slots, cpl);
     }
-    const int lpr = sgx_next_pow2(n_feat);
-    return dtype == SGX_F16 ? launch_lpr<f16, 1>(a, lpr > 64 ? 64 : lpr)
-                            : launch_lpr<float, 1>(a, lpr > 64 ? 64 : lpr);
+    int slots = sgx_next_pow2(n_feat);
+    if (slots > 64) slots = 64;
+    return dtype == SGX_F16 ? launch_lpr<f16, 1>(a, slots, 1) : launch_lpr<float, 1>(a, slots, 1);
 }
 
 extern "C" int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,

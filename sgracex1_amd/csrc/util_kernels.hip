@@ -182,6 +182,7 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
     long_first.push_back((int32_t)task_row.size());
     sgx_plan *p = new sgx_plan();
     p->n_rows = n_rows;
+    p->nnz = rp[(size_t)n_rows];
     p->long_threshold = kLongThreshold;
     p->chunk = kChunk;
     p->n_long = (int)long_row.size();
