@@ -174,6 +174,135 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weights-stationary form (fp16, M_fea <= 128): the reference keeps its W tile on chip for the
+// whole pass over X (B_accel, K.cpp:3038-3051); here a wavefront keeps the W fragments of its
+// NTW column tiles for ALL of K in registers (KS k-steps x NTW tiles x 4 VGPRs <= 80) and walks
+// row tiles of X persistently, so W is fetched once per wavefront and the loop only streams X in
+// and H out -- no LDS, no barriers, next tile's X fragments requested before this tile's MFMAs.
+// G = ceil(P/16 / NTW) column groups; consecutive wavefronts (one workgroup) take the G groups of
+// the same row tile, so the G-fold re-read of X hits L1/L2.
+// ---------------------------------------------------------------------------------------
+template <int KS, int NTW, int MT>
+__global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
+    int n_rows, int M, int P, int col_groups, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt,
+    int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t total_waves = (int64_t)gridDim.x * (kBlock / 64);
+    const int cg = (int)(gw % col_groups);
+    const int64_t stream = gw / col_groups, n_streams = total_waves / col_groups;
+    if (stream >= n_streams) return;                            // leftover wavefronts of the last workgroup
+    const int n_base = cg * NTW * 16;
+
+    f16x8 a[KS][NTW];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = n_base + nt * 16 + l15;
+            a[ks][nt] = load_k8(Wt + (int64_t)n * ldw, ks * 32 + 8 * lq, M, n < P, true);
+        }
+
+    const int64_t n_tiles = (n_rows + MT * 16 - 1) / (MT * 16);
+    f16x8 b[KS][MT], b_next[KS][MT];
+    int64_t tile = stream;
+    if (tile < n_tiles) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m = tile * (MT * 16) + mt * 16 + l15;
+                b_next[ks][mt] = load_k8(X + m * ldx, ks * 32 + 8 * lq, M, m < n_rows, true);
+            }
+    }
+    for (; tile < n_tiles; tile += n_streams) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) b[ks][mt] = b_next[ks][mt];
+        const int64_t next = tile + n_streams;
+        if (next < n_tiles) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int64_t m = next * (MT * 16) + mt * 16 + l15;
+                    b_next[ks][mt] = load_k8(X + m * ldx, ks * 32 + 8 * lq, M, m < n_rows, true);
+                }
+        }
+        f32x4 acc[MT][NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][nt], b[ks][mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = tile * (MT * 16) + mt * 16 + l15;
+            if (m >= n_rows) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = n_base + nt * 16 + 4 * lq;
+                f16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
+                f16 *dst = H + m * ldh + n;
+                if (h_aligned && n + 4 <= ldh) {
+                    *reinterpret_cast<f16x4 *>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < ldh) dst[j] = o[j];
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int NTW>
+int launch_stationary(int n_rows, int M, int P, int nt_total, const void *X, int64_t ldx, const void *Wt, int64_t ldw,
+                      void *H, int64_t ldh, int ha, hipStream_t s)
+{
+    constexpr int MT = 2;
+    const int groups = (nt_total + NTW - 1) / NTW;
+    const int64_t n_tiles = ((int64_t)n_rows + MT * 16 - 1) / (MT * 16);
+    // persistent grid: 8 workgroups per CU, trimmed to the work there is, whole column-group sets only
+    int64_t waves = (int64_t)256 * 8 * (kBlock / 64);
+    if (waves > n_tiles * groups) waves = n_tiles * groups;
+    waves = (waves + groups - 1) / groups * groups;
+    const unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL((xw_dense_stationary_f16_kernel<KS, NTW, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
+                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+// picks (KS, NTW) for the stationary kernel; SGX_ERR_UNSUPPORTED = use the tiled kernel
+int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H,
+                   int64_t ldh, int ha, hipStream_t s)
+{
+    // measured (tools/bench_configs.py): 100 -> 256 on 2.4 M rows 1.31 -> 0.66 ms; with K > 128 the W
+    // fragments leave room for one column tile only and the re-reads of X cost more than they save
+    // (602 -> 128: 0.23 -> 0.38 ms), so longer K stays on the tiled kernel
+    if (M > 128 || n_rows < 8192) return SGX_ERR_UNSUPPORTED;
+    const int nt_total = (int)((ldh + 15) / 16);               // pad columns P..ldh-1 are produced (as zeros) too
+    const int ks = (M + 31) / 32;
+#define SGX_ST(KS_, NTW_) return launch_stationary<KS_, NTW_>(n_rows, M, P, nt_total, X, ldx, Wt, ldw, H, ldh, ha, s)
+    if (ks <= 2) { if (nt_total >= 8) SGX_ST(2, 8); if (nt_total >= 4) SGX_ST(2, 4); if (nt_total >= 2) SGX_ST(2, 2); SGX_ST(2, 1); }
+    if (ks <= 4) { if (nt_total >= 4) SGX_ST(4, 4); if (nt_total >= 2) SGX_ST(4, 2); SGX_ST(4, 1); }
+    SGX_ST(4, 1);
+#undef SGX_ST
+}
+
 template <int NT, int MT>
 int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
                 int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s)
@@ -211,6 +340,10 @@ extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows,
     const int xa = ((uintptr_t)X % 16 == 0) && ((ldx * es) % 16 == 0);
     const int wa = ((uintptr_t)Wt % 16 == 0) && ((ldw * es) % 16 == 0);
     const int ha = ((uintptr_t)H % (4 * es) == 0) && ((ldh * es) % (4 * es) == 0);
+    if (dtype == SGX_F16) {
+        const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s);
+        if (rc != SGX_ERR_UNSUPPORTED) return rc;
+    }
     // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
     for (int p_base = 0; p_base < ldh; p_base += 256) {
         const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);

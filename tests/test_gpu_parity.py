@@ -165,10 +165,12 @@ def test_spmm_long_rows_split_path(sgx, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
-@pytest.mark.parametrize("M,P", [(7, 64), (64, 64), (100, 256), (602, 128), (33, 21), (64, 7), (1433, 16), (40, 300)])
-def test_xw_dense_mfma(sgx, oracle, dtype, M, P):
+@pytest.mark.parametrize("M,P", [(7, 64), (64, 64), (100, 256), (602, 128), (33, 21), (64, 7), (1433, 16), (40, 300),
+                                 (128, 128), (200, 48), (256, 24)])
+@pytest.mark.parametrize("n", [1037, 9001])
+def test_xw_dense_mfma(sgx, oracle, dtype, M, P, n):
+    """n = 1037 runs the tiled kernel, n = 9001 (fp16, M <= 640) the weights-stationary one."""
     rng = np.random.default_rng(M * 1000 + P)
-    n = 1037
     X = rng.standard_normal((n, M)).astype(np.float32)
     W = (rng.standard_normal((M, P)) / np.sqrt(M)).astype(np.float32)
     if dtype == torch.float16:
