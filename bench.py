@@ -11,9 +11,12 @@ BASELINE.json's target is quoted on: S-100M -- N = 2^22 nodes, 100 M uniformly r
 edges (+ self loops, coalesced), GCN symmetric normalisation, fp16, hidden = 64, Cora-like
 sparse input features (F_in = 1433, density 1.27 %).  Output: ONE JSON line on rank 0.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns
-2^22 rows / 100 M edges of a graph with N * 2^22 nodes; per layer H = X.W is exchanged with one
-RCCL all-gather over xGMI and aggregated locally (sgracex1_amd/dist.py).
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a
+partition of 2^22 rows / 100 M edges of a graph with N * 2^22 nodes; --cut (default 0.1) of a
+partition's edges point anywhere in the graph, the rest stay inside it (N = 1 is then exactly the
+single-GPU graph).  Per layer the rows of H = X.W that other partitions reference are exchanged
+over xGMI (RCCL all-to-all of halo rows; --exchange allgather / --cut 1.0 = every row) and
+aggregated locally (sgracex1_amd/dist.py).
 """
 import argparse
 import json
@@ -43,12 +46,17 @@ def parse():
     ap.add_argument("--workload", default="s100m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frac", type=float, default=0.25)
+    ap.add_argument("--cut", type=float, default=0.1,
+                    help="N > 1: share of a partition's edges whose column is drawn from the whole graph "
+                         "(1.0 = no locality at all, every H row is a halo row)")
+    ap.add_argument("--exchange", choices=("halo", "allgather"), default=None,
+                    help="N > 1: rows of H exchanged per layer (default: halo, allgather when --cut >= 0.5)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="rocprofv3 --pmc result for the dominant kernel (HBM bytes per launch)")
     return ap.parse_args()
 
 
-def make_inputs(torch, graphs, ops, wl, rank, world, device):
+def make_inputs(torch, graphs, ops, wl, rank, world, device, cut=1.0):
     """Synthetic graph + features + weights of the stated shape, generated on the device."""
     n, hidden, f_in = wl["n"], wl["hidden"], wl["f_in"]
     seed = 12345 + rank
@@ -63,7 +71,13 @@ def make_inputs(torch, graphs, ops, wl, rank, world, device):
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         row = torch.randint(0, n, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
-        col = torch.randint(0, n_global, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        # a partitioned graph: an edge leaves its row's partition with probability `cut` (then its
+        # column is uniform over all nodes), otherwise it stays inside the partition
+        col_any = torch.randint(0, n_global, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        col_own = torch.randint(0, n, (wl["edges"],), generator=g, device=device, dtype=torch.int64) + rank * n
+        leaves = torch.rand(wl["edges"], generator=g, device=device) < cut
+        col = torch.where(leaves, col_any, col_own)
+        del col_any, col_own, leaves
         loops = torch.arange(n, device=device, dtype=torch.int64)
         row = torch.cat([row, loops])
         col = torch.cat([col, loops + rank * n])
@@ -173,7 +187,8 @@ def main():
             dist.init_process_group(backend_name)
 
     wl = WORKLOADS[args.workload]
-    A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device)
+    A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device, cut=args.cut)
+    exchange = args.exchange or ("allgather" if args.cut >= 0.5 else "halo")
     n, hidden = wl["n"], wl["hidden"]
     nnz = A.nnz
     A.plan  # build the row schedules outside the timed region (once per graph)
@@ -194,7 +209,17 @@ def main():
     else:
         backend = sdist.hip_backend()
         bounds = [g * n for g in range(world + 1)]
-        table = torch.empty((n * world, hidden), dtype=torch.float16, device=device)
+        halo = None
+        if exchange == "halo":
+            # once per graph: which rows of H every peer needs, and A's columns renumbered to the
+            # compact table [own rows | halo rows by owner]
+            halo = sdist.build_halo_plan(A.col, bounds, rank)
+            A_run = ops.Csr(A.rowptr, halo.col_compact, A.val, halo.n_table)
+            A_run.plan
+            table = torch.empty((halo.n_table, hidden), dtype=torch.float16, device=device)
+        else:
+            A_run = A
+            table = torch.empty((n * world, hidden), dtype=torch.float16, device=device)
 
         def timed_spmm(adj, tab, relu, pair, out):
             if pair is not None:
@@ -209,8 +234,12 @@ def main():
             p2 = ev[2 * i + 1] if timed else None
             b1 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p1, D1))
             b2 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p2, D2))
-            sdist.layer_allgather(b1, A, X, W1t, True, bounds, h_global=table)
-            sdist.layer_allgather(b2, A, D1, W2t, False, bounds, h_global=table)
+            if halo is not None:
+                sdist.layer_halo(b1, A_run, X, W1t, True, halo, table=table)
+                sdist.layer_halo(b2, A_run, D1, W2t, False, halo, table=table)
+            else:
+                sdist.layer_allgather(b1, A_run, X, W1t, True, bounds, h_global=table)
+                sdist.layer_allgather(b2, A_run, D1, W2t, False, bounds, h_global=table)
 
     def barrier():
         if world > 1:
@@ -267,7 +296,10 @@ def main():
                    "f_in": wl["f_in"], "hidden": hidden,
                    "layer1": "gemm_mode=0 sparse X, relu=1" if wl["x_density"] else "gemm_mode=1 dense X, relu=1",
                    "layer2": "gemm_mode=1 dense X, relu=0",
-                   "exchange": "none" if world == 1 else "RCCL all-gather of H per layer"},
+                   "exchange": "none" if world == 1 else
+                   (f"RCCL all-to-all of halo rows of H per layer ({sum(halo.recv_counts)} rows received per rank)"
+                    if halo is not None else "RCCL all-gather of H per layer"),
+                   "cut": None if world == 1 else args.cut},
         "roofline": {"bound": "hbm", "kernel": "spmm_sblock_kernel<f16,8,8> (A.H aggregation)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,

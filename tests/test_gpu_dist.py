@@ -53,16 +53,19 @@ def test_two_ranks_one_gpu_match_single_rank():
         assert all(os.path.exists(os.path.join(tmp, f"ok{r}")) for r in range(2))
 
 
-def test_bench_multi_rank_path_rehearsal():
-    """bench.py as the driver launches it for N > 1, on the small workload, 2 ranks on one GPU over gloo."""
+@pytest.mark.parametrize("extra,expect", [([], "RCCL all-to-all of halo rows"),
+                                          (["--cut", "1.0"], "RCCL all-gather")])
+def test_bench_multi_rank_path_rehearsal(extra, expect):
+    """bench.py as the driver launches it for N > 1, on the small workload, 2 ranks on one GPU over gloo:
+    the default partitioned graph (halo exchange) and the no-locality case (all-gather)."""
     env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90 + len(extra)),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--workload", "small"], env=env, capture_output=True, text=True, timeout=600)
+                          "--workload", "small"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert rec["config"]["exchange"].startswith("RCCL all-gather")
+    assert rec["config"]["exchange"].startswith(expect)
