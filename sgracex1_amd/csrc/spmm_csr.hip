@@ -26,6 +26,9 @@
 #endif
 #include <stdlib.h>
 
+#ifndef SGX_SPMM_PIECES
+#define SGX_SPMM_PIECES 1            // pieces of LPR edges per loop iteration (gathers in flight x PIECES)
+#endif
 #ifndef SGX_SPMM_BLOCKS_PER_CU
 #define SGX_SPMM_BLOCKS_PER_CU 512   // grid cap (2.18 vs 2.21 ms at 64 on S-100M); rows beyond it are grid-strided
 #endif
@@ -50,43 +53,62 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
                                                  __amdgpu_buffer_rsrc_t rsrc, const T *__restrict__ table,
                                                  unsigned ld_bytes, const unsigned *chunk_off)
 {
-    int c_next = 0;
-    T a_next = (T)0;
-    if (e0 + sub < e1) {
-        c_next = __builtin_nontemporal_load(col + e0 + sub);    // streamed once: keep L2 for H
-        a_next = __builtin_nontemporal_load(val + e0 + sub);
-    }
-    for (int base = e0; base < e1; base += stride) {
-        const int c = c_next;
-        const float a = Elem<T>::to_f32(a_next);
-        // the next piece's (column, value) pair is requested before this piece's gathers
-        const int nidx = base + stride + sub;
-        c_next = 0;
-        a_next = (T)0;
-        if (nidx < e1) {
-            c_next = __builtin_nontemporal_load(col + nidx);
-            a_next = __builtin_nontemporal_load(val + nidx);
+    // PIECES pieces of LPR edges are handled per iteration: their (column, value) pairs arrive with
+    // one load each (requested one iteration ahead) and all their gathers are issued before the first
+    // is consumed -- SGX_SPMM_PIECES * min(LPR, 8/CPL) * CPL gathers in flight per lane.
+    constexpr int PIECES = SGX_SPMM_PIECES;
+    int c_next[PIECES];
+    T a_next[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+        const int idx = e0 + p * stride + sub;
+        c_next[p] = 0;
+        a_next[p] = (T)0;
+        if (idx < e1) {
+            c_next[p] = __builtin_nontemporal_load(col + idx);  // streamed once: keep L2 for H
+            a_next[p] = __builtin_nontemporal_load(val + idx);
         }
-        const int n = e1 - base;                                // valid edges in this piece (>= 1)
-        constexpr int kInFlight = 8 / CPL;                      // edges whose gathers are issued together
+    }
+    for (int base = e0; base < e1; base += PIECES * stride) {
+        int c[PIECES];
+        float a[PIECES];
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) {
+            c[p] = c_next[p];
+            a[p] = Elem<T>::to_f32(a_next[p]);
+            // the next iteration's (column, value) pairs are requested before this iteration's gathers
+            const int nidx = base + (PIECES + p) * stride + sub;
+            c_next[p] = 0;
+            a_next[p] = (T)0;
+            if (nidx < e1) {
+                c_next[p] = __builtin_nontemporal_load(col + nidx);
+                a_next[p] = __builtin_nontemporal_load(val + nidx);
+            }
+        }
+        constexpr int kInFlight = 8 / CPL;                      // edges of one piece whose gathers go together
         constexpr int UNR = LPR < kInFlight ? LPR : kInFlight;
 #pragma unroll 1
         for (int t0 = 0; t0 < LPR; t0 += UNR) {
-            if (t0 >= n) break;
+            if (t0 >= e1 - base) break;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int t = t0 + u;
-                const int cc = __shfl(c, t, LPR);
-                const float aa = __shfl(a, t, LPR);
+            for (int p = 0; p < PIECES; ++p) {
+                const int n = e1 - base - p * stride;            // valid edges in this piece (may be <= 0)
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    const bool valid = t < n && chunk_off[j] != kOOB;
-                    if constexpr (!BIG) {
-                        Gather<T, VEC>::run(acc + j * VEC, aa, rsrc, valid ? (unsigned)cc * ld_bytes + chunk_off[j] : kOOB);
-                    } else {
-                        if (valid)
-                            GatherPtr<T, VEC>::run(acc + j * VEC, aa, reinterpret_cast<const char *>(table) +
-                                                                          (size_t)(unsigned)cc * ld_bytes + chunk_off[j]);
+                for (int u = 0; u < UNR; ++u) {
+                    const int t = t0 + u;
+                    const int cc = __shfl(c[p], t, LPR);
+                    const float aa = __shfl(a[p], t, LPR);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        const bool valid = t < n && chunk_off[j] != kOOB;
+                        if constexpr (!BIG) {
+                            Gather<T, VEC>::run(acc + j * VEC, aa, rsrc,
+                                                valid ? (unsigned)cc * ld_bytes + chunk_off[j] : kOOB);
+                        } else {
+                            if (valid)
+                                GatherPtr<T, VEC>::run(acc + j * VEC, aa, reinterpret_cast<const char *>(table) +
+                                                                              (size_t)(unsigned)cc * ld_bytes + chunk_off[j]);
+                        }
                     }
                 }
             }
@@ -123,14 +145,20 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 }
 
 // ---------------------------------------------------------------------------------------
-// sblock path: one group of LPR lanes per row, 64/LPR rows per wavefront.
+// One launch, two kinds of workgroup.  Workgroups [0, split_blocks) run the split path: one
+// wavefront per (long row, 512-edge chunk), all 64/LPR lane groups on the same row, fp32 partial
+// rows.  The others run the sblock path: one group of LPR lanes per row, 64/LPR rows per
+// wavefront.  Putting both in one grid lets the heavy chunks start first and the short rows fill
+// in around them (on R-MAT the two paths as separate launches took 0.98 + 1.24 ms back to back).
 // ---------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
-__global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
+__global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
     T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store,
-    const int32_t *__restrict__ row_order)
+    const int32_t *__restrict__ row_order,
+    int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
+    float *__restrict__ partial, int ldp)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
     constexpr int LANE_COLS = CPL * VEC;          // columns per lane
@@ -138,11 +166,41 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
-    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
 
+    if ((int)blockIdx.x < split_blocks) {
+        // ---- split path ----
+        const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        if (task >= n_tasks) return;
+        const int e0 = task_e0[task], e1 = task_e1[task];
+        for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+            const int col0 = c0 + sub * LANE_COLS;
+            unsigned chunk_off[CPL];
+            float acc[LANE_COLS];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
+#pragma unroll
+            for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
+            accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes,
+                                                    chunk_off);
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int i = 0; i < LANE_COLS; ++i) acc[i] += __shfl_xor(acc[i], off);
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < LANE_COLS; ++i)
+                    if (col0 + i < n_feat) partial[(int64_t)task * ldp + col0 + i] = acc[i];
+            }
+        }
+        return;
+    }
+
+    // ---- sblock path ----
+    const int64_t wave = (int64_t)(blockIdx.x - split_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)(gridDim.x - split_blocks) * (kBlock / 64);
     // n_rows = number of work items; row_order (from the plan) lists the rows in degree order so
     // that the 64/LPR rows a wavefront owns need about the same number of steps
     for (int64_t r0 = wave * RPW; r0 < n_rows; r0 += n_waves * RPW) {
@@ -172,47 +230,6 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_sblock_kernel(
                     if (col0 + j * VEC < n_feat)
                         store_row<T, VEC>(D + r * ldd, col0 + j * VEC, n_feat, acc + j * VEC, relu, vec_store != 0);
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// split path: one wavefront per (long row, edge chunk); fp32 partial rows.
-// ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CPL, bool BIG>
-__global__ __launch_bounds__(kBlock) void spmm_split_kernel(
-    int n_tasks, int n_feat, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
-    const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes,
-    unsigned ld_bytes, float *__restrict__ partial, int ldp)
-{
-    constexpr int LANE_COLS = CPL * VEC;
-    constexpr int TILE = LPR * LANE_COLS;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane % LPR;
-    const int grp = lane / LPR;
-    const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (task >= n_tasks) return;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(H), 0, h_bytes, 0x00020000);
-    const int e0 = task_e0[task], e1 = task_e1[task];
-    for (int c0 = 0; c0 < n_feat; c0 += TILE) {
-        const int col0 = c0 + sub * LANE_COLS;
-        unsigned chunk_off[CPL];
-        float acc[LANE_COLS];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j)
-            chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
-#pragma unroll
-        for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
-        accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes, chunk_off);
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-            for (int i = 0; i < LANE_COLS; ++i) acc[i] += __shfl_xor(acc[i], off);
-        if (grp == 0) {
-#pragma unroll
-            for (int i = 0; i < LANE_COLS; ++i)
-                if (col0 + i < n_feat) partial[(int64_t)task * ldp + col0 + i] = acc[i];
         }
     }
 }
@@ -263,21 +280,21 @@ int grid_for_rows(int64_t n_rows, int rows_per_wave)
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
 int launch_one_impl(const LaunchArgs &a)
 {
-    const int long_thr = (a.plan && a.plan->n_long > 0) ? a.plan->long_threshold : 0;
-    const int32_t *order = a.plan ? a.plan->row_order : nullptr;
-    const int n_work = order ? a.plan->n_ordered : a.n_rows;
-    if (n_work > 0) {
-        hipLaunchKernelGGL((spmm_sblock_kernel<T, VEC, LPR, CPL, BIG>), dim3(grid_for_rows(n_work, 64 / LPR)),
-                           dim3(kBlock), 0, a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val,
-                           (const T *)a.H, a.h_bytes, a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order);
+    const sgx_plan *p = a.plan;
+    const int long_thr = (p && p->n_long > 0) ? p->long_threshold : 0;
+    const int32_t *order = p ? p->row_order : nullptr;
+    const int n_work = order ? p->n_ordered : a.n_rows;
+    const int n_tasks = long_thr > 0 ? p->n_tasks : 0;
+    const int split_blocks = (n_tasks + kBlock / 64 - 1) / (kBlock / 64);
+    const int row_blocks = n_work > 0 ? grid_for_rows(n_work, 64 / LPR) : 0;
+    if (split_blocks + row_blocks > 0) {
+        hipLaunchKernelGGL((spmm_kernel<T, VEC, LPR, CPL, BIG>), dim3(split_blocks + row_blocks), dim3(kBlock), 0,
+                           a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
+                           a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order, split_blocks, n_tasks,
+                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, a.partial, a.ldp);
         SGX_LAUNCH_CHECK();
     }
-    if (long_thr > 0) {
-        const sgx_plan *p = a.plan;
-        hipLaunchKernelGGL((spmm_split_kernel<T, VEC, LPR, CPL, BIG>), dim3((p->n_tasks + 3) / 4), dim3(kBlock), 0,
-                           a.stream, p->n_tasks, a.n_feat, p->task_e0, p->task_e1, a.col, (const T *)a.val,
-                           (const T *)a.H, a.h_bytes, a.ld_bytes, a.partial, a.ldp);
-        SGX_LAUNCH_CHECK();
+    if (n_tasks > 0) {
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((spmm_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, a.partial,

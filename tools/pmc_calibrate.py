@@ -3,7 +3,7 @@
 THIS path's access pattern (MI355X_MICROARCH.md "HBM": FETCH_SIZE is only calibrated for wide
 streaming reads).  Run under  rocprofv3 --pmc FETCH_SIZE ...  and  --pmc WRITE_SIZE ...
 
-  launch A  spmm_sblock_kernel on a permutation graph: N = 2^24 rows, one edge per row to a
+  launch A  spmm_kernel on a permutation graph: N = 2^24 rows, one edge per row to a
             distinct random row of H [N, 64] fp16 (2 GiB, far beyond L2 + Infinity Cache), so
             every 128-byte row of H is gathered exactly once:
               reads  = N*128 (H) + N*(4+2) (col,val) + (N+1)*4 (rowptr)   writes = N*128

@@ -23,8 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(pattern):
-    files = glob.glob(pattern)
-    return list(csv.DictReader(open(files[0]))) if files else []
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)        # the newest run wins
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def counter(rows, kernel_sub, name):
@@ -50,14 +50,14 @@ def main():
     # per-dispatch durations of the aggregation kernel: the A.H launches are the long ones
     trace = load(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
-                  if "spmm_sblock_kernel" in r["Kernel_Name"])
+                  if "spmm_kernel" in r["Kernel_Name"])
     big = [d for d in durs if d > 0.6 * durs[-1]] if durs else []
     bench_line = None
     for ln in open(os.path.join(src, "bench_trace.log")):
         if ln.startswith("{"):
             bench_line = json.loads(ln)
 
-    K = "spmm_sblock_kernel"
+    K = "spmm_kernel"
     fetch = counter(load(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")), K, "FETCH_SIZE")
     write = counter(load(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv")), K, "WRITE_SIZE")
     l2 = load(os.path.join(src, "pmc_l2", "*", "*_counter_collection.csv"))
@@ -81,7 +81,7 @@ def main():
     n_cal = 1 << 24
     cal_true = n_cal * 128 + n_cal * 6 + (n_cal + 1) * 4
     summary = {
-        "workload": wl, "tag": tag, "kernel": "spmm_sblock_kernel<f16,8,8> (A.H launches)",
+        "workload": wl, "tag": tag, "kernel": "spmm_kernel<f16,8,8> (A.H launches)",
         "launch_ns_kernel_trace": {"avg": sum(big) / len(big), "min": big[0], "max": big[-1], "n": len(big)},
         "launch_ms_bench_events": {"avg": rl["avg_launch_ms"], "min": rl["min_launch_ms"]},
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,

@@ -16,8 +16,8 @@ CSRC = os.path.join(ROOT, "sgracex1_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out", "sweep")
 
 VARIANTS = {}
-for mw, nt, bpc in itertools.product((1, 5, 8), (0, 1), (16, 64, 512)):
-    VARIANTS[f"mw{mw}_nt{nt}_bpc{bpc}"] = dict(SGX_SPMM_MINWAVES=mw, SGX_SPMM_NT_STORE=nt, SGX_SPMM_BLOCKS_PER_CU=bpc)
+for pieces, mw in itertools.product((1, 2, 3), (1, 3)):
+    VARIANTS[f"pieces{pieces}_mw{mw}"] = dict(SGX_SPMM_PIECES=pieces, SGX_SPMM_MINWAVES=mw)
 
 
 def build():
@@ -46,9 +46,15 @@ sys.path.insert(0, %r)
 from sgracex1_amd import graphs, ops
 from sgracex1_amd.hipevents import Event
 gen = sys.argv[1]
-A = graphs.rmat_graph(22, 100_000_000) if gen == "rmat" else graphs.uniform_graph(1 << 22, 100_000_000)
-H = torch.rand((A.n_cols, 64), device="cuda").half()
-D = torch.empty((A.n_rows, 64), device="cuda", dtype=torch.float16)
+P = 64
+if gen == "rmat":
+    A = graphs.rmat_graph(22, 100_000_000)
+elif gen == "reddit":
+    A = graphs.uniform_graph(232_965, 114_600_000, seed=3); P = 128
+else:
+    A = graphs.uniform_graph(1 << 22, 100_000_000)
+H = torch.rand((A.n_cols, P), device="cuda").half()
+D = torch.empty((A.n_rows, P), device="cuda", dtype=torch.float16)
 A.plan
 for _ in range(3): ops.spmm(A, H, relu=True, out=D)
 torch.cuda.synchronize()
@@ -74,6 +80,8 @@ def run(gen):
 
 if __name__ == "__main__":
     if "--run" in sys.argv:
-        run("rmat" if "--rmat" in sys.argv else "uniform")
+        for gen in ("uniform", "rmat", "reddit"):
+            print("==", gen, flush=True)
+            run(gen)
     else:
         build()
