@@ -193,6 +193,16 @@ int sgx_csr_validate(const int32_t *rowPtr, const int32_t *columnIndex, int n_ro
  * (SG.py:1222, :1245).  rowPtr [n_rows+1]. */
 int sgx_coo_to_csr(const int32_t *rowIndex, int64_t nnz, int n_rows, int32_t *rowPtr, void *stream);
 
+/* Weight gradient of the layer's backward pass, grad_W = X^T . G with G = adj @ grad_output already
+ * aggregated by sgx_spmm_csr (FPYNQ.backward, MOL cell 16; the reference runs it in torch on the CPU).
+ * X [n_rows][ldx] fp16|fp32 dense, G [n_rows][ldg] fp32, out [M][ldo] fp32 (exact fp32 fma chains,
+ * slab sums added in a fixed order).  The other two products of the backward pass are existing
+ * entry points: adj @ g = sgx_spmm_csr, grad_x = G . W^T = sgx_xw_dense(G, Wt := W [M][P]); for a CSR
+ * X, X^T . G = sgx_spmm_csr over the CSR of X^T. */
+size_t sgx_xt_g_workspace_bytes(int n_rows, int M, int P);
+int sgx_xt_g(int dtype_x, int n_rows, int M, int P, const void *X, int64_t ldx, const float *G, int64_t ldg,
+             float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ReLU backward of RPYNQ (MOL cell 16): grad[i] = (out[i] == 0) ? 0 : grad[i], in place. */
 int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
                            void *stream);

@@ -25,6 +25,7 @@ SYMBOLS = [
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
     "sgx_spmm_csr", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
     "sgx_gat_aggregate", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
+    "sgx_xt_g", "sgx_xt_g_workspace_bytes",
     "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_version", "sgx_status_string",
 ]
@@ -96,6 +97,10 @@ def _load():
     lib.sgx_coo_to_csr.restype = c_int
     lib.sgx_relu_mask_backward.argtypes = [c_int, vp, c_int, vp, c_i64, vp]
     lib.sgx_relu_mask_backward.restype = c_int
+    lib.sgx_xt_g_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sgx_xt_g_workspace_bytes.restype = sz
+    lib.sgx_xt_g.argtypes = [c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp, sz, vp]
+    lib.sgx_xt_g.restype = c_int
     lib.sgx_event_create.argtypes = [ctypes.POINTER(vp)]
     lib.sgx_event_create.restype = c_int
     lib.sgx_event_destroy.argtypes = [vp]

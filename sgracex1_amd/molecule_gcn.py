@@ -83,20 +83,33 @@ class FPYNQ(torch.autograd.Function):
             fea = as_csr(input.detach(), ACC_DTYPE)
         output_acc = my_ip.run_layer(A, fea, Wt)
         ctx.adj = A
+        ctx.fea_csr = None if dense else fea
         ctx.save_for_backward(input, weights, output_acc)
         return output_acc
 
     @staticmethod
     def backward(ctx, grad_output):
+        """All three products on the device kernels, in fp32 as the reference's CPU backward:
+        G = adj @ g (CSR aggregation), grad_W = X^T @ G (sgx_xt_g, or the aggregation kernel over
+        the CSR of X^T when the layer's features were sparse), grad_x = G @ W^T (MFMA X.W kernel)."""
         input, weights, output = ctx.saved_tensors
         A = ctx.adj
-        input = input.float()
-        if input.layout != torch.strided:
-            input = input.to_dense()
-        g = grad_output.float()
-        ag = ops.spmm(A.to(torch.float32), g.contiguous())          # adj @ g   (fp32, like the CPU path)
-        grad_weights = input.t() @ ag                               # input^T @ adj @ g
-        grad_input = ag @ weights.float().t()                       # adj @ g @ W^T
+        g = grad_output.float().contiguous()
+        ag = ops.spmm(A.to(torch.float32), g)                                # adj @ g
+        if ctx.fea_csr is not None:
+            Xt = ctx.fea_csr.__dict__.get("_transposed")
+            if Xt is None:
+                Xt = ops.csr_transpose(ctx.fea_csr.to(torch.float32))
+                ctx.fea_csr._transposed = Xt
+            grad_weights = ops.spmm(Xt, ag)                                   # X^T @ (adj @ g)
+        else:
+            x = input if input.dtype in (torch.float16, torch.float32) else input.float()
+            grad_weights = ops.xt_g(x.contiguous(), ag)
+        grad_input = None
+        if ctx.needs_input_grad[2]:
+            grad_input = ops.xw_dense(ag, weights.detach().float().contiguous())   # (adj @ g) @ W^T
+            if grad_input.stride(0) != grad_input.shape[1]:
+                grad_input = grad_input.contiguous()
         return None, None, grad_input, grad_weights
 
 

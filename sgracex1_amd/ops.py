@@ -274,6 +274,32 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
     return (out, E, S) if want_edge_outputs else out
 
 
+def xt_g(X, G):
+    """grad_W = X^T @ G (sgx_xt_g): X [n, M] fp16|fp32 dense, G [n, P] fp32 -> [M, P] fp32."""
+    _dev2d(X, "X")
+    _dev2d(G, "G")
+    if G.dtype != torch.float32:
+        raise TypeError("G must be float32 (the backward pass runs in fp32, MOL cell 16)")
+    n, M = X.shape
+    P = G.shape[1]
+    out = torch.empty((M, P), dtype=torch.float32, device=X.device)
+    nbytes = lib.sgx_xt_g_workspace_bytes(n, M, P)
+    ws = _workspace(X.device, nbytes)
+    check(lib.sgx_xt_g(dtype_code(X.dtype), n, M, P, _ptr(X), X.stride(0), _ptr(G), G.stride(0), _ptr(out), P,
+                       _ptr(ws), ws.numel(), _stream()), "sgx_xt_g")
+    return out
+
+
+def csr_transpose(A):
+    """CSR of A^T (values kept, same dtype); features are fixed across epochs, so callers cache it."""
+    row = torch.repeat_interleave(torch.arange(A.n_rows, device=A.col.device, dtype=torch.int64),
+                                  (A.rowptr[1:] - A.rowptr[:-1]).long())
+    key = A.col.to(torch.int64) * A.n_rows + row
+    order = torch.argsort(key)
+    return Csr.from_coo(A.col[order].contiguous(), row[order].to(torch.int32).contiguous(), A.val[order].contiguous(),
+                        A.n_cols, A.n_rows)
+
+
 def relu_mask_backward_(out, grad):
     """grad[out == 0] = 0 in place (RPYNQ.backward, MOL cell 16)."""
     _dev(out, "out")

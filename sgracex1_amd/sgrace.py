@@ -151,8 +151,11 @@ class FPYNQ_GAT(torch.autograd.Function):
         else:
             P = A.to(torch.float32)
             grad_attention = torch.zeros((2 * weights.shape[1], 1), device=g.device)
-        grad_input = ops.spmm(P, (g @ weights.t()).contiguous())
-        grad_weights = input.t() @ ops.spmm(P, g.contiguous())
+        pg = ops.spmm(P, g.contiguous())                                       # P @ g
+        grad_input = ops.xw_dense(pg, weights.contiguous())                    # (P @ g) @ W^T == P @ (g @ W^T)
+        if grad_input.stride(0) != grad_input.shape[1]:
+            grad_input = grad_input.contiguous()
+        grad_weights = ops.xt_g(input.contiguous(), pg)                        # X^T @ (P @ g)
         return none, none, none, none, grad_input, grad_weights, grad_attention, none, none, none
 
 

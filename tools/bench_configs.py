@@ -118,6 +118,20 @@ def main():
         A = ops.csr_from_edge_index(b.edge_index, b.num_nodes)
         X = ops.Csr.from_dense(b.x, torch.float16)
         gcn_two_layer("c1 molecule_gcn MUTAG batch", A, X, rand_w(64, 7, gen), rand_w(64, 64, gen), 200, small=True)
+        # one training step of the notebook's model (forward on the kernels, backward on the kernels, Adam)
+        from sgracex1_amd import molecule_gcn as MG, pynq_shim
+        model = MG.GCN_PYNQ(64, 7, 2, pynq_shim.Overlay("gnn_all.bit").mmult_top_0).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        crit = torch.nn.CrossEntropyLoss()
+
+        def train_step():
+            opt.zero_grad()
+            crit(model(1, b.x, b.edge_index, b.batch), b.y).backward()
+            opt.step()
+
+        print(json.dumps({"config": "c1 molecule_gcn training step (188 graphs)", "ms_train_step": timed(train_step, 50),
+                          "reference": "RFSoC forward 14.8 + 39.4 ms, ARM backward 0.19-0.28 s per layer (MOL cell 20 output)"}),
+              flush=True)
 
     if "c2" in want:
         from _fixtures import GOLD, load
