@@ -291,7 +291,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 storage, f32 accumulate", "data": "synthetic",
+        "dtype": "f16 (f32 accumulate)", "data": "synthetic",
         "config": {"workload": args.workload, "nodes_per_gpu": n, "edges_per_gpu": nnz, "generator": wl["gen"],
                    "f_in": wl["f_in"], "hidden": hidden,
                    "layer1": "gemm_mode=0 sparse X, relu=1" if wl["x_density"] else "gemm_mode=1 dense X, relu=1",

@@ -1,34 +1,46 @@
-"""Run-time flag module, same names as the reference's demo/*/config.py (emulation/config.py:1-31).
+"""Run-time flags of the SGRACE host library, exposed under the names the reference's per-board
+`config.py` modules use (demo/emulation/config.py, demo/{rfsoc42,ultra96,zcu104}/config.py), so
+that code written against `import config; config.acc = 1` keeps working:
 
-Only the flags that reach the hot path are live here; the quantisation flags of the SGRACE
-bitstream (fake_quantization, hardware_quantize, w_qbits) are accepted for source compatibility
-but must stay at their "off" values -- the quantised kernel is outside the fp16/fp32 path this
-package implements.
+    import sgracex1_amd.config as config
+
+Each flag is declared once in `_FLAGS` below with what it means HERE; the module then publishes
+them as plain module attributes.  Only the flags that reach the GPU hot path are live.  The
+quantisation switches of the SGRACE bitstream are accepted for source compatibility but must stay
+at their "off" values -- the int8/1-bit kernel is outside the fp16/fp32 path of this package.
 """
-import numpy as np
+import numpy as _np
 
-device = "cuda"              # reference default "cpu"; the accelerator here is the GPU itself
-hidden_channels = 16
-layer_count = 1
-load_weights = 1
+_FLAGS = {
+    # -- where and how a layer runs ------------------------------------------------------------
+    "device": ("cuda", "torch device of the tensors; the accelerator is the GPU itself"),
+    "acc": (1, "forward path: 1 = HIP kernels, 0 = the dense torch formulation (parity twin)"),
+    "accb": (0, "backward offload register path of the GAT bitstream (gemm_mode 2): not offered; "
+                "backward always runs on the device kernels"),
+    "compute_attention": (0, "0 = GCN aggregate A.H, 1 = single-head GAT edge softmax (register gat_mode)"),
+    "float_type": (_np.float32, "element type of the layer buffers; np.float16 selects the HALF build's type"),
+    "hidden_channels": (16, "default hidden width of the demo models"),
+    "head_count": (1, "accepted, unused (the reference marks it 'not in use' as well)"),
+    # -- accepted, no effect on this path --------------------------------------------------------
+    "layer_count": (1, "layers per hardware call on the FPGA"),
+    "load_weights": (1, "FPGA weight preload switch"),
+    "stream_mode": (0, "FPGA streaming I/O switch"),
+    "profiling": (0, "print per-layer host timings"),
+    "show_max_min": (0, "print value ranges"),
+    "min_output": (1, "quiet mode"),
+    # -- quantised bitstream: must stay off -------------------------------------------------------
+    "fake_quantization": (0, "emulate the int8 bitstream in torch: unsupported (layers raise if set)"),
+    "hardware_quantize": (0, "int8 bitstream quantiser"),
+    "w_qbits": (32, "weight bits of the quantised bitstream"),
+    # -- buffer capacities of the PYNQ allocation step (informational here) ----------------------
+    "N_adj": (20480, "max nodes"), "M_adj": (20480, "max nodes"), "M_fea": (2048, "max input features"),
+    "NNZ_adj": (1_000_000, "max adjacency non-zeros"), "NNZ_fea": (4_000_000, "max feature non-zeros"),
+}
 
-accb = 0                     # backward on the accelerator (the reference's gemm_mode=2 bitstream path): not offered
-acc = 1                      # 1: forward through the HIP kernels; 0: plain torch `adj @ x @ W` (the parity twin)
-show_max_min = 0
-min_output = 1
-profiling = 0
-fake_quantization = 0        # reference default 1 (emulates the int8 bitstream); unsupported here
-hardware_quantize = 0
-compute_attention = 0        # 0: GCN aggregate, 1: GAT edge softmax (register gat_mode)
-stream_mode = 0
-head_count = 1               # "not in use" in the reference too (emulation/config.py:18)
+globals().update({name: default for name, (default, _doc) in _FLAGS.items()})
+P_w = hidden_channels  # noqa: F821  (published by the line above)
 
-N_adj = 20480
-M_adj = 20480
-M_fea = 2048
-P_w = hidden_channels
-NNZ_adj = 1000000
-NNZ_fea = 4000000
-w_qbits = 32
 
-float_type = np.float32      # element type of the accelerator buffers (SG.py:1545); np.float16 selects the HALF build's type
+def describe():
+    """name -> (current value, meaning), for notebooks that want to print the configuration."""
+    return {name: (globals()[name], doc) for name, (_d, doc) in _FLAGS.items()}
