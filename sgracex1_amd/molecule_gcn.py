@@ -214,8 +214,12 @@ class GCN_PYNQ(torch.nn.Module):
                 columnIndex_adj_buffer, values_adj_buffer, B_buffer, D_buffer)
         if acc == 1:
             # pynq_adj = to_dense_adj(edge_index)._to_sparse_csr() of the notebook, built from the
-            # edge list directly (same CSR, no dense N x N intermediate)
-            adj = ops.csr_from_edge_index(edge_index, x.shape[0], dtype=ACC_DTYPE)
+            # edge list directly (same CSR, no dense N x N intermediate); the batch of an epoch loop is
+            # the same tensor every time, so the result is kept
+            key = (edge_index.data_ptr(), edge_index.shape[1], x.shape[0], edge_index._version)
+            if getattr(self, "_adj_key", None) != key:
+                self._adj_key, self._adj_csr = key, ops.csr_from_edge_index(edge_index, x.shape[0], dtype=ACC_DTYPE)
+            adj = self._adj_csr
         else:
             adj = torch.squeeze(to_dense_adj(edge_index, num_nodes=x.shape[0]))
         dense, relu = 0, 1

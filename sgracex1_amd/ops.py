@@ -116,6 +116,12 @@ class Csr:
             self._plan = Plan(self.rowptr)
         return self._plan
 
+    @property
+    def wants_plan(self):
+        """Building a plan costs one device->host copy and a stream sync; matrices this small finish
+        in microseconds on any schedule, so they run without one unless a plan already exists."""
+        return self._plan is not None or self.nnz >= 65536
+
     def to(self, dtype):
         return self if self.val.dtype == dtype else Csr(self.rowptr, self.col, self.val.to(dtype), self.n_cols,
                                                         self._plan)
@@ -167,7 +173,7 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_
     n_feat = H.shape[1] if n_feat is None else n_feat
     if out is None:
         out = torch.empty((adj.n_rows, n_feat), dtype=H.dtype, device=H.device)
-    plan = adj.plan if use_plan else None
+    plan = adj.plan if (use_plan and adj.wants_plan) else None
     sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
     scratch = _workspace(H.device, sbytes) if sbytes else None
     check(lib.sgx_spmm_csr(code, acc_mode, spmm_block, int(bool(relu)), adj.n_rows, H.shape[0], n_feat,
@@ -224,7 +230,7 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
             raise ValueError("feature CSR does not match adjacency / weights")
         d.rowPtr_fea, d.columnIndex_fea, d.values_fea = (fea.rowptr.data_ptr(), fea.col.data_ptr(),
                                                          fea.val.data_ptr())
-        if use_plan:
+        if use_plan and fea.wants_plan:
             d.plan_fea = fea.plan.handle
     else:
         _dev(fea, "fea")
@@ -232,7 +238,7 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
             raise ValueError(f"dense features must be [{adj.n_cols}, {M_fea}] {Wt.dtype}")
         d.values_fea = fea.data_ptr()
     d.rowPtr_adj, d.columnIndex_adj, d.values_adj = adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr()
-    if use_plan:
+    if use_plan and adj.wants_plan:
         d.plan_adj = adj.plan.handle
     d.B = Wt.data_ptr()
     if out is None:
