@@ -203,6 +203,14 @@ size_t sgx_xt_g_workspace_bytes(int n_rows, int M, int P);
 int sgx_xt_g(int dtype_x, int n_rows, int M, int P, const void *X, int64_t ldx, const float *G, int64_t ldg,
              float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Readout + classifier head of the graph-classification model (MOL cell 18 tail) in one launch:
+ * pooled[g][:] = mean of X rows [graph_ptr[g], graph_ptr[g+1])  (global_mean_pool over a sorted
+ * `batch` vector), logits[g][c] = bias[c] + W[c][:] . pooled[g][:]  (torch Linear, W [C][F] fp32).
+ * pooled or logits may be NULL (then W, bias are not read); bias may be NULL. */
+int sgx_readout_mean_linear(int dtype, int n_graphs, int F, int C, const void *X, int64_t ldx,
+                            const int32_t *graph_ptr, const float *W, const float *bias, float *pooled,
+                            float *logits, void *stream);
+
 /* ReLU backward of RPYNQ (MOL cell 16): grad[i] = (out[i] == 0) ? 0 : grad[i], in place. */
 int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
                            void *stream);

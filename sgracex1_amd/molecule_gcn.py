@@ -227,6 +227,13 @@ class GCN_PYNQ(torch.nn.Module):
         x = x.relu() if acc == 0 else self.reluh(x)
         dense, relu = 1, 0
         x = self.conv2(acc, dense, relu, x, adj, *bufs)
+        if acc == 1 and not self.training and not torch.is_grad_enabled():
+            # inference: pooling and the Linear head in one launch (dropout is the identity in eval);
+            # `batch` is sorted (graphs are contiguous), so a graph is a row segment
+            counts = torch.bincount(batch)
+            ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=batch.device)
+            ptr[1:] = torch.cumsum(counts, 0)
+            return ops.readout_mean_linear(x.contiguous(), ptr, self.lin.weight, self.lin.bias)
         x = x.float()
         x = global_mean_pool(x, batch)
         x = F.dropout(x, p=0.5, training=self.training)

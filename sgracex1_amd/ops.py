@@ -306,6 +306,24 @@ def csr_transpose(A):
                         A.n_cols, A.n_rows)
 
 
+def readout_mean_linear(x, graph_ptr, weight=None, bias=None, want_pooled=False):
+    """global_mean_pool over contiguous graphs + Linear head in one launch (sgx_readout_mean_linear).
+    x [n, F] fp16|fp32, graph_ptr int32 [n_graphs+1], weight [C, F] fp32, bias [C] fp32."""
+    _dev2d(x, "x")
+    _dev(graph_ptr, "graph_ptr")
+    n_graphs, F = graph_ptr.numel() - 1, x.shape[1]
+    C = 0 if weight is None else weight.shape[0]
+    pooled = torch.empty((n_graphs, F), dtype=torch.float32, device=x.device) if (want_pooled or weight is None) else None
+    logits = torch.empty((n_graphs, C), dtype=torch.float32, device=x.device) if weight is not None else None
+    w = None if weight is None else _dev(weight.detach().float().contiguous(), "weight")
+    b = None if bias is None else _dev(bias.detach().float().contiguous(), "bias")
+    check(lib.sgx_readout_mean_linear(dtype_code(x.dtype), n_graphs, F, C, _ptr(x), x.stride(0), _ptr(graph_ptr),
+                                      _ptr(w), _ptr(b), _ptr(pooled), _ptr(logits), _stream()), "sgx_readout_mean_linear")
+    if weight is None:
+        return pooled
+    return (logits, pooled) if want_pooled else logits
+
+
 def relu_mask_backward_(out, grad):
     """grad[out == 0] = 0 in place (RPYNQ.backward, MOL cell 16)."""
     _dev(out, "out")

@@ -60,3 +60,24 @@ def test_training_step_gradients_match_torch_twin():
         ref = grads[0][k]
         err = (grads[1][k] - ref).abs().max() / (ref.abs().max() + 1e-12)
         assert err < 2e-2, (k, float(err))                        # fp16 forward vs fp32 twin
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_readout_mean_linear_matches_torch(dtype):
+    """Fused global_mean_pool + Linear head ("next" row f3) against the two torch ops, with an empty
+    graph and ragged graph sizes."""
+    from sgracex1_amd import ops
+    from sgracex1_amd.pyg_lite import global_mean_pool
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2)
+    sizes = torch.tensor([17, 1, 0, 300, 28, 5], device="cuda")
+    batch = torch.repeat_interleave(torch.arange(6, device="cuda"), sizes)
+    x = torch.randn((int(sizes.sum()), 64), generator=g, device="cuda").to(dtype)
+    lin = torch.nn.Linear(64, 3).cuda()
+    ptr = torch.zeros(7, dtype=torch.int32, device="cuda")
+    ptr[1:] = torch.cumsum(sizes, 0)
+    logits, pooled = ops.readout_mean_linear(x, ptr, lin.weight, lin.bias, want_pooled=True)
+    want_pool = global_mean_pool(x.float(), batch, size=6)
+    assert torch.allclose(pooled, want_pool, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(logits, lin(want_pool), rtol=1e-4, atol=1e-5)
+    assert torch.equal(pooled[2], torch.zeros(64, device="cuda"))
