@@ -4,6 +4,7 @@
 // (MOL cell 16), and the row schedule (sgx_plan).
 #include "sgx_internal.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -223,7 +224,9 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
             spent += (double)mx * kGroup;
         }
         p->natural_utilization = spent > 0 ? (float)(useful / spent) : 1.0f;
-        if (p->natural_utilization < kReorderBelow && n_rows - p->n_long > 0) {
+        float reorder_below = kReorderBelow;
+        if (const char *f = getenv("SGX_PLAN_REORDER_BELOW")) reorder_below = (float)atof(f);      // tuning override
+        if (p->natural_utilization < reorder_below && n_rows - p->n_long > 0) {
             // counting sort by step count, longest first, ascending row id inside a bucket
             std::vector<int64_t> start(kStepsMax + 1, 0);
             for (int r = 0; r < n_rows; ++r) {

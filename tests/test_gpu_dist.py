@@ -69,3 +69,26 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["config"]["exchange"].startswith(expect)
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    """`python bench.py` (N = 1) on the small workload: one JSON line with the driver's fields, the
+    roofline object timed on the launch stream, and the CPU baseline from the oracle port."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "4",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 4 and rec["unit"] == "edges/s" and rec["vs_baseline"] is None
+    assert rec["config"]["workload"] == "small" and "model" not in rec["config"]
+    rl = rec["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9 and rl["launches_timed"] == 8
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s"
+    assert rec["value"] > cb["value"]
