@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--cut", type=float, default=0.1,
                     help="N > 1: share of a partition's edges whose column is drawn from the whole graph "
                          "(1.0 = no locality at all, every H row is a halo row)")
-    ap.add_argument("--exchange", choices=("halo", "allgather"), default=None,
-                    help="N > 1: rows of H exchanged per layer (default: halo, allgather when --cut >= 0.5)")
+    ap.add_argument("--exchange", choices=("halo-overlap", "halo", "allgather"), default=None,
+                    help="N > 1: rows of H exchanged per layer (default: halo-overlap = halo rows travel while the "
+                         "own-partition edges are aggregated; allgather when --cut >= 0.5)")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="rocprofv3 --pmc result for the dominant kernel (HBM bytes per launch)")
     return ap.parse_args()
@@ -188,7 +189,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device, cut=args.cut)
-    exchange = args.exchange or ("allgather" if args.cut >= 0.5 else "halo")
+    exchange = args.exchange or ("allgather" if args.cut >= 0.5 else "halo-overlap")
     n, hidden = wl["n"], wl["hidden"]
     nnz = A.nnz
     A.plan  # build the row schedules outside the timed region (once per graph)
@@ -210,13 +211,21 @@ def main():
         backend = sdist.hip_backend()
         bounds = [g * n for g in range(world + 1)]
         halo = None
-        if exchange == "halo":
+        overlap = exchange == "halo-overlap"
+        agg_nnz = nnz                       # edges of the launch the roofline events bracket
+        if exchange in ("halo", "halo-overlap"):
             # once per graph: which rows of H every peer needs, and A's columns renumbered to the
             # compact table [own rows | halo rows by owner]
             halo = sdist.build_halo_plan(A.col, bounds, rank)
             A_run = ops.Csr(A.rowptr, halo.col_compact, A.val, halo.n_table)
             A_run.plan
             table = torch.empty((halo.n_table, hidden), dtype=torch.float16, device=device)
+            if overlap:
+                own, far = sdist.split_own_halo(A.rowptr, halo.col_compact, A.val, halo.n_own)
+                A_own, A_far = ops.Csr(*own, halo.n_own), ops.Csr(*far, max(1, sum(halo.recv_counts)))
+                A_own.plan, A_far.plan
+                halo_table = torch.empty((max(1, sum(halo.recv_counts)), hidden), dtype=torch.float16, device=device)
+                agg_nnz = A_own.nnz
         else:
             A_run = A
             table = torch.empty((n * world, hidden), dtype=torch.float16, device=device)
@@ -234,7 +243,23 @@ def main():
             p2 = ev[2 * i + 1] if timed else None
             b1 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p1, D1))
             b2 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p2, D2))
-            if halo is not None:
+            if overlap:
+                def first_pass(pair):
+                    def run(a, t):
+                        if pair is not None:
+                            pair[0].record(stream)
+                        part = ops.spmm_acc(a, t, partial_out=True)
+                        if pair is not None:
+                            pair[1].record(stream)
+                        return part
+                    return run
+                o1 = sdist.Backend(backend.xw, None, first_pass(p1),
+                                   lambda a, t, part, r: ops.spmm_acc(a, t, relu=r, acc_in=part, out=D1))
+                o2 = sdist.Backend(backend.xw, None, first_pass(p2),
+                                   lambda a, t, part, r: ops.spmm_acc(a, t, relu=r, acc_in=part, out=D2))
+                sdist.layer_halo_overlap(o1, A_own, A_far, X, W1t, True, halo, halo_table=halo_table)
+                sdist.layer_halo_overlap(o2, A_own, A_far, D1, W2t, False, halo, halo_table=halo_table)
+            elif halo is not None:
                 sdist.layer_halo(b1, A_run, X, W1t, True, halo, table=table)
                 sdist.layer_halo(b2, A_run, D1, W2t, False, halo, table=table)
             else:
@@ -271,7 +296,10 @@ def main():
     agg_avg_ms = sum(agg_ms) / len(agg_ms)
     n_cols = A.n_cols
     es = 2
-    b_alg = nnz * (4 + es + hidden * es) + (n + 1) * 4 + n * hidden * es       # SURVEY 8d, no-reuse gather model
+    if world == 1:
+        agg_nnz = nnz
+    out_es = 4 if (world > 1 and exchange == "halo-overlap") else es   # the overlapped first pass stores fp32 sums
+    b_alg = agg_nnz * (4 + es + hidden * es) + (n + 1) * 4 + n * hidden * out_es   # SURVEY 8d, no-reuse gather model
     b_min = nnz * (4 + es) + (n + 1) * 4 + (n + n_cols) * hidden * es          # compulsory traffic
     achieved = b_alg / (agg_avg_ms * 1e-3) / 1e9
     traffic = None
@@ -298,13 +326,15 @@ def main():
                    "layer2": "gemm_mode=1 dense X, relu=0",
                    "exchange": "none" if world == 1 else
                    (f"RCCL all-to-all of halo rows of H per layer ({sum(halo.recv_counts)} rows received per rank)"
+                    + (", overlapped with the aggregation of the own-partition edges" if exchange == "halo-overlap" else "")
                     if halo is not None else "RCCL all-gather of H per layer"),
                    "cut": None if world == 1 else args.cut},
-        "roofline": {"bound": "hbm", "kernel": "spmm_kernel<f16,8,8> (A.H aggregation)",
+        "roofline": {"bound": "hbm", "kernel": "spmm_kernel<f16,8,8> (A.H aggregation"
+                     + (", own-partition pass)" if (world > 1 and exchange == "halo-overlap") else ")"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                      "avg_launch_ms": agg_avg_ms, "min_launch_ms": agg_ms[0], "launches_timed": len(agg_ms),
-                     "agg_edges_per_s": nnz / (agg_avg_ms * 1e-3)},
+                     "agg_edges_per_s": agg_nnz / (agg_avg_ms * 1e-3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)

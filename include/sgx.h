@@ -154,6 +154,16 @@ int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu,
                  const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream);
 size_t sgx_spmm_scratch_bytes(const sgx_plan *plan, int n_feat);
 
+/* The same aggregation in two passes over disjoint edge sets, for the multi-GPU path (the edges
+ * whose column lives in the rank's own partition while the halo rows travel over xGMI, then the
+ * halo edges): pass 1 writes the fp32 sums to acc_out (D = NULL), pass 2 starts from acc_in and
+ * writes D = act(acc_in + A.H).  acc_* are [n_rows][ld_acc] fp32; either may be NULL. */
+int sgx_spmm_csr_acc(int dtype, int relu, int n_rows, int n_cols, int n_feat,
+                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                     const void *H, int64_t ldh, void *D, int64_t ldd,
+                     const float *acc_in, float *acc_out, int64_t ld_acc,
+                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream);
+
 /* X.W with dense X = loop_fea / compute1 in gemm_mode 1 (K.cpp:2932, :2605, :847-865),
  * on the matrix cores:  H[r][0:P] = sum_k X[r][k] * Wt[p][k].
  * X [n_rows][ldx], Wt [P][ldw] (= B), H [n_rows][ldh]; columns P..ldh-1 of H are zeroed. */

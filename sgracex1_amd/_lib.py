@@ -23,7 +23,7 @@ SYMBOLS = [
     "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_natural_utilization",
     "sgx_plan_reordered",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
-    "sgx_spmm_csr", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
+    "sgx_spmm_csr", "sgx_spmm_csr_acc", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
     "sgx_gat_aggregate", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
     "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear",
     "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
@@ -79,6 +79,9 @@ def _load():
     lib.sgx_spmm_csr.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_i64, vp, c_i64,
                                  vp, vp, sz, vp]
     lib.sgx_spmm_csr.restype = c_int
+    lib.sgx_spmm_csr_acc.argtypes = [c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_i64, vp, c_i64,
+                                     vp, vp, c_i64, vp, vp, sz, vp]
+    lib.sgx_spmm_csr_acc.restype = c_int
     lib.sgx_spmm_scratch_bytes.argtypes = [vp, c_int]
     lib.sgx_spmm_scratch_bytes.restype = sz
     lib.sgx_xw_dense.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp]

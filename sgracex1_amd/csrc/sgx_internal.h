@@ -63,4 +63,5 @@ int sgx_refhalf_dense(int spmm_block, int n_rows, int M, int n_feat, const void 
 int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,
                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                     const void *H, int64_t ldh, void *D, int64_t ldd,
-                    const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream);
+                    const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
+                    const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0);

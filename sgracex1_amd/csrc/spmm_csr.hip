@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(
     T *__restrict__ D, int64_t ldd, int relu, int long_threshold, int vec_store,
     const int32_t *__restrict__ row_order,
     int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
-    float *__restrict__ partial, int ldp)
+    float *__restrict__ partial, int ldp,
+    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
     constexpr int LANE_COLS = CPL * VEC;          // columns per lane
@@ -223,8 +224,19 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(
                 chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
 #pragma unroll
             for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
+            // two-pass aggregation (own-partition edges while the halo rows travel, then the halo
+            // edges): the second pass starts from the first pass's fp32 sums
+            if (acc_in && live) {
+#pragma unroll
+                for (int i = 0; i < LANE_COLS; ++i)
+                    if (col0 + i < n_feat) acc[i] = acc_in[r * ld_acc + col0 + i];
+            }
             accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, chunk_off);
-            if (live) {
+            if (live && acc_out) {
+#pragma unroll
+                for (int i = 0; i < LANE_COLS; ++i)
+                    if (col0 + i < n_feat) acc_out[r * ld_acc + col0 + i] = acc[i];
+            } else if (live) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j)
                     if (col0 + j * VEC < n_feat)
@@ -237,16 +249,19 @@ __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_split_finalize_kernel(
     int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
-    const float *__restrict__ partial, int ldp, T *__restrict__ D, int64_t ldd, int relu)
+    const float *__restrict__ partial, int ldp, T *__restrict__ D, int64_t ldd, int relu,
+    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc)
 {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t total = (int64_t)n_long * n_feat;
     if (gid >= total) return;
     const int l = (int)(gid / n_feat), j = (int)(gid % n_feat);
-    float s = 0.0f;
+    const int64_t row = long_row[l];
+    float s = acc_in ? acc_in[row * ld_acc + j] : 0.0f;
     for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
+    if (acc_out) { acc_out[row * ld_acc + j] = s; return; }
     T v = Elem<T>::from_f32(s);
-    D[(int64_t)long_row[l] * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
+    D[row * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -264,6 +279,9 @@ struct LaunchArgs {
     int ldp;
     int vec_store;
     bool big;
+    const float *acc_in;
+    float *acc_out;
+    int64_t ld_acc;
     hipStream_t stream;
 };
 
@@ -291,14 +309,15 @@ int launch_one_impl(const LaunchArgs &a)
         hipLaunchKernelGGL((spmm_kernel<T, VEC, LPR, CPL, BIG>), dim3(split_blocks + row_blocks), dim3(kBlock), 0,
                            a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
                            a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order, split_blocks, n_tasks,
-                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, a.partial, a.ldp);
+                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, a.partial, a.ldp, a.acc_in,
+                           a.acc_out, a.ld_acc);
         SGX_LAUNCH_CHECK();
     }
     if (n_tasks > 0) {
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((spmm_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, a.partial,
-                           a.ldp, (T *)a.D, a.ldd, a.relu);
+                           a.ldp, (T *)a.D, a.ldd, a.relu, a.acc_in, a.acc_out, a.ld_acc);
         SGX_LAUNCH_CHECK();
     }
     return SGX_OK;
@@ -356,12 +375,15 @@ size_t sgx_spmm_scratch_bytes(const sgx_plan *plan, int n_feat)
 int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,
                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                     const void *H, int64_t ldh, void *D, int64_t ldd,
-                    const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream)
+                    const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
+                    const float *acc_in, float *acc_out, int64_t ld_acc)
 {
     (void)spmm_block;
-    if (n_rows < 0 || n_cols < 0 || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
+    if (n_rows < 0 || n_cols < 0 || n_feat < 1 || ldh < n_feat) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
-    if (!rowPtr || !D) return SGX_ERR_NULL;
+    if (!rowPtr || (!D && !acc_out)) return SGX_ERR_NULL;
+    if (D && ldd < n_feat) return SGX_ERR_SHAPE;
+    if ((acc_in || acc_out) && (ld_acc < n_feat || acc_mode != SGX_ACC_F32)) return SGX_ERR_SHAPE;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
     if (acc_mode == SGX_ACC_REF_HALF) {
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
@@ -381,6 +403,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.H = H;
     a.h_bytes = big ? 0u : (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es); a.big = big;
     a.D = D; a.ldd = ldd; a.plan = plan; a.stream = stream;
+    a.acc_in = acc_in; a.acc_out = acc_out; a.ld_acc = ld_acc;
     a.partial = (float *)scratch;
     a.ldp = (int)sgx_align_up((size_t)n_feat, 4);
     if (plan && plan->n_tasks > 0) {
@@ -406,5 +429,16 @@ extern "C" int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu, i
                             const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
 {
     return sgx_spmm_launch(dtype, acc_mode, spmm_block, relu, n_rows, n_cols, n_feat, rowPtr, columnIndex, values,
-                           H, ldh, D, ldd, plan, scratch, scratch_bytes, (hipStream_t)stream);
+                           H, ldh, D, ldd, plan, scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, 0);
+}
+
+extern "C" int sgx_spmm_csr_acc(int dtype, int relu, int n_rows, int n_cols, int n_feat,
+                                const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                                const void *H, int64_t ldh, void *D, int64_t ldd,
+                                const float *acc_in, float *acc_out, int64_t ld_acc,
+                                const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (D && acc_out) return SGX_ERR_SHAPE;           // one destination: the final rows or the fp32 partial
+    return sgx_spmm_launch(dtype, SGX_ACC_F32, 1, relu, n_rows, n_cols, n_feat, rowPtr, columnIndex, values, H, ldh, D,
+                           ldd, plan, scratch, scratch_bytes, (hipStream_t)stream, acc_in, acc_out, ld_acc);
 }

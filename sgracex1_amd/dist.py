@@ -122,9 +122,13 @@ def build_halo_plan(col_global: torch.Tensor, bounds: List[int], rank: int, grou
 
 @dataclass
 class Backend:
-    """Local compute: xw(fea_local, Wt) -> H_local [n_local, P];  spmm(adj_csr, table, relu) -> D_local."""
+    """Local compute: xw(fea_local, Wt) -> H_local [n_local, P];  spmm(adj_csr, table, relu) -> D_local;
+    for the overlapped exchange also spmm_partial(adj, table) -> fp32 sums and
+    spmm_finish(adj, table, partial, relu) -> D_local = act(partial + adj @ table)."""
     xw: Callable
     spmm: Callable
+    spmm_partial: Optional[Callable] = None
+    spmm_finish: Optional[Callable] = None
 
 
 def hip_backend():
@@ -136,7 +140,9 @@ def hip_backend():
             return ops.spmm(fea, W, relu=False)
         return ops.xw_dense(fea, Wt)
 
-    return Backend(xw=xw, spmm=lambda adj, table, relu: ops.spmm(adj, table, relu=relu))
+    return Backend(xw=xw, spmm=lambda adj, table, relu: ops.spmm(adj, table, relu=relu),
+                   spmm_partial=lambda adj, table: ops.spmm_acc(adj, table, partial_out=True),
+                   spmm_finish=lambda adj, table, partial, relu: ops.spmm_acc(adj, table, relu=relu, acc_in=partial))
 
 
 def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None):
@@ -171,3 +177,45 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
     all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
     return backend.spmm(adj_compact, table, relu)
+
+
+def split_own_halo(rowptr, col_compact, val, n_own):
+    """Cuts a rank's CSR rows into the edges whose column is an own row (index < n_own) and the edges
+    that reference halo rows (renumbered from 0); the order of edges inside a row is kept.
+    Returns ((rowptr, col, val) own, (rowptr, col, val) halo)."""
+    n_rows = rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(n_rows, device=rowptr.device), deg)
+    own = col_compact < n_own
+    parts = []
+    for mask, shift in ((own, 0), (~own, n_own)):
+        cnt = torch.bincount(row[mask], minlength=n_rows)
+        rp = torch.zeros(n_rows + 1, dtype=torch.int32, device=rowptr.device)
+        rp[1:] = torch.cumsum(cnt, 0)
+        parts.append((rp, (col_compact[mask] - shift).to(torch.int32).contiguous(), val[mask].contiguous()))
+    return parts[0], parts[1]
+
+
+def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu, plan: HaloPlan, group=None,
+                       halo_table=None):
+    """The halo exchange hidden behind the aggregation of the own-partition edges: start the
+    all-to-all of the halo rows, sum the own edges into fp32 partials meanwhile, wait, add the halo
+    edges (the PIPO overlap of the reference, K.cpp:3651-3749, moved to the inter-GPU step).
+    adj_own: columns = own row ids; adj_halo: columns = rows of the received halo table."""
+    h_local = backend.xw(fea_local, Wt)
+    P = h_local.shape[1]
+    n_halo = sum(plan.recv_counts)
+    if halo_table is None:
+        halo_table = torch.empty((n_halo, P), dtype=h_local.dtype, device=h_local.device)
+    packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
+    staged = _host_staged(packed, group) or (halo_table.is_cuda and dist.get_backend(group) == "gloo")
+    work = None
+    if staged or dist.get_backend(group) == "gloo":
+        all_to_all_rows(halo_table, packed, plan.recv_counts, plan.send_counts, group=group)      # no async on gloo
+    else:
+        work = dist.all_to_all_single(halo_table, packed, output_split_sizes=plan.recv_counts,
+                                      input_split_sizes=plan.send_counts, group=group, async_op=True)
+    partial = backend.spmm_partial(adj_own, h_local if h_local.is_contiguous() else h_local.contiguous())
+    if work is not None:
+        work.wait()
+    return backend.spmm_finish(adj_halo, halo_table, partial, relu)

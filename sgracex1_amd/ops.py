@@ -183,6 +183,30 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_
     return out
 
 
+def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_plan=True):
+    """Two-pass aggregation (sgx_spmm_csr_acc): with partial_out the fp32 sums acc_in + A @ H are
+    returned; otherwise D = act(acc_in + A @ H) in H's dtype."""
+    _dev2d(H, "H")
+    code = dtype_code(H.dtype)
+    n_feat = H.shape[1]
+    if acc_in is not None:
+        _dev(acc_in, "acc_in")
+        if acc_in.dtype != torch.float32 or acc_in.shape != (adj.n_rows, n_feat):
+            raise ValueError("acc_in must be float32 [n_rows, n_feat]")
+    acc_out = torch.empty((adj.n_rows, n_feat), dtype=torch.float32, device=H.device) if partial_out else None
+    if not partial_out and out is None:
+        out = torch.empty((adj.n_rows, n_feat), dtype=H.dtype, device=H.device)
+    plan = adj.plan if (use_plan and adj.wants_plan) else None
+    sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
+    scratch = _workspace(H.device, sbytes) if sbytes else None
+    check(lib.sgx_spmm_csr_acc(code, int(bool(relu)), adj.n_rows, H.shape[0], n_feat, _ptr(adj.rowptr), _ptr(adj.col),
+                               _ptr(adj.val), _ptr(H), H.stride(0), None if partial_out else _ptr(out),
+                               0 if partial_out else out.stride(0), _ptr(acc_in), _ptr(acc_out), n_feat,
+                               plan.handle if plan is not None else None, _ptr(scratch), sbytes, _stream()),
+          "sgx_spmm_csr_acc")
+    return acc_out if partial_out else out
+
+
 def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
     """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M]."""
     _dev2d(X, "X")

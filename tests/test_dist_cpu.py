@@ -55,7 +55,14 @@ def _worker(rank, world, port, tmp, balance_nnz):
             out = O.spmm_f32(int(relu), (adj.rowptr.numpy(), adj.col.numpy(), adj.val.numpy()), table.numpy())
             return torch.as_tensor(out)
 
-        backend = D.Backend(xw=xw, spmm=spmm)
+        def spmm_partial(adj, table):
+            return spmm(adj, table, False)
+
+        def spmm_finish(adj, table, partial, relu):
+            out = partial + spmm(adj, table, False)
+            return torch.clamp(out, min=0) if relu else out
+
+        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish)
         trp, tci, tva = torch.as_tensor(rp), torch.as_tensor(ci), torch.as_tensor(va)
         bounds = D.row_partition(n, world, trp if balance_nnz else None)
         assert bounds[0] == 0 and bounds[-1] == n and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
@@ -88,6 +95,13 @@ def _worker(rank, world, port, tmp, balance_nnz):
         assert int(plan.col_compact.max()) < plan.n_table if lci.numel() else True
         d2 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan)
         assert torch.equal(d1, d2)                                                   # same sums, same order
+        # exchange (iii): the halo rows travel while the own-partition edges are summed
+        own, halo = D.split_own_halo(lrp, plan.col_compact, lva, plan.n_own)
+        assert int(own[0][-1]) + int(halo[0][-1]) == lci.numel()
+        assert (own[1] < plan.n_own).all() and (halo[1] < sum(plan.recv_counts)).all() if lci.numel() else True
+        d3 = D.layer_halo_overlap(backend, LocalCsr(*own, plan.n_own), LocalCsr(*halo, sum(plan.recv_counts)), Xl, Wt,
+                                  True, plan)
+        np.testing.assert_allclose(d3.numpy(), want[lo:hi], rtol=1e-5, atol=1e-5)
         # bytes moved: the halo exchange never receives more rows than the all-gather would
         assert sum(plan.recv_counts) <= n - (hi - lo)
         sent = torch.tensor([sum(plan.send_counts)], dtype=torch.int64)

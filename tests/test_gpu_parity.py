@@ -333,3 +333,32 @@ def test_spmm_table_beyond_4gib(sgx):
     assert torch.allclose(got, want, rtol=2e-3, atol=2e-3)
     assert torch.allclose(got[:, 1], torch.as_tensor(np.add.reduceat(np.append(va, 0), rp[:-1]) * (deg > 0),
                                                       device="cuda", dtype=torch.float32), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_two_pass_aggregation(sgx, dtype):
+    """sgx_spmm_csr_acc: the edges split into two disjoint sets and aggregated in two passes (fp32
+    partial in between) against the single pass, with long rows in both passes."""
+    rng = np.random.default_rng(21)
+    n_rows, n_cols, P = 2000, 3000, 64
+    rp, ci, va = _rand_csr(rng, n_rows, n_cols, 12.0, long_rows=[(5, 1400), (900, 700)])
+    va = (va * 0.1).astype(np.float32)
+    H = torch.randn((n_cols, P), device="cuda").to(dtype)
+    A = _csr(sgx, (rp, ci, va), n_cols, dtype)
+    A.plan
+    single = sgx.spmm(A, H, relu=True)
+    first = ci < 1500                                                  # "own" columns / "halo" columns
+    row = np.repeat(np.arange(n_rows), np.diff(rp))
+    parts = []
+    for m in (first, ~first):
+        prp = np.zeros(n_rows + 1, np.int32)
+        prp[1:] = np.cumsum(np.bincount(row[m], minlength=n_rows))
+        B = _csr(sgx, (prp, ci[m], va[m]), n_cols, dtype)
+        B.plan
+        parts.append(B)
+    partial = sgx.spmm_acc(parts[0], H, partial_out=True)
+    assert partial.dtype == torch.float32
+    two = sgx.spmm_acc(parts[1], H, relu=True, acc_in=partial)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-5)
+    assert torch.allclose(two.float(), single.float(), **tol)
+    assert (two == single).float().mean() > 0.97
