@@ -211,9 +211,9 @@ def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu,
     staged = _host_staged(packed, group) or (halo_table.is_cuda and dist.get_backend(group) == "gloo")
     work = None
     if staged or dist.get_backend(group) == "gloo":
-        all_to_all_rows(halo_table, packed, plan.recv_counts, plan.send_counts, group=group)      # no async on gloo
+        all_to_all_rows(halo_table[:n_halo], packed, plan.recv_counts, plan.send_counts, group=group)      # no async on gloo
     else:
-        work = dist.all_to_all_single(halo_table, packed, output_split_sizes=plan.recv_counts,
+        work = dist.all_to_all_single(halo_table[:n_halo], packed, output_split_sizes=plan.recv_counts,
                                       input_split_sizes=plan.send_counts, group=group, async_op=True)
     partial = backend.spmm_partial(adj_own, h_local if h_local.is_contiguous() else h_local.contiguous())
     if work is not None:
