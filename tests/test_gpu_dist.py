@@ -99,3 +99,63 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s"
     assert rec["value"] > cb["value"]
+
+
+_RCCL_SELF = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+from sgracex1_amd import dist as D, graphs, ops
+n, k, f_in, p = 5000, 700, 80, 64
+A_own = graphs.uniform_graph(n, 40000, seed=11, device=dev)
+g = torch.Generator(device=dev); g.manual_seed(12)
+X = torch.rand((n, f_in), generator=g, device=dev).half()
+Wt = ((torch.rand((p, f_in), generator=g, device=dev) - 0.5) / 4).half()
+# a one-rank world that sends k of its own rows to itself: the RCCL calls, their stream ordering and
+# the asynchronous wait are the ones a multi-GPU node runs
+send_rows = torch.randperm(n, generator=g, device=dev)[:k].sort().values
+far = graphs.uniform_graph(n, 9000, seed=13, device=dev)
+far_col = (far.col.long() % k).int()
+A_far = ops.Csr(far.rowptr, far_col, far.val, k)
+plan = D.HaloPlan(bounds=[0, n], rank=0, col_compact=A_own.col, send_rows=send_rows, send_counts=[k], recv_counts=[k],
+                  n_own=n)
+backend = D.hip_backend()
+H = ops.xw_dense(X, Wt)
+part = ops.spmm_acc(A_own, H, partial_out=True)
+want = ops.spmm_acc(A_far, H.index_select(0, send_rows).contiguous(), relu=True, acc_in=part)
+for _ in range(3):                                          # repeated: a missing wait would show as stale halo rows
+    got = D.layer_halo_overlap(backend, A_own, A_far, X, Wt, True, plan)
+    assert torch.equal(got, want)
+# the one-pass halo form over the compact table [own rows | received rows]
+rp = A_own.rowptr.long() + A_far.rowptr.long()
+own_deg, far_deg = A_own.rowptr.diff().long(), A_far.rowptr.diff().long()
+rows_o = torch.repeat_interleave(torch.arange(n, device=dev), own_deg)
+rows_f = torch.repeat_interleave(torch.arange(n, device=dev), far_deg)
+rows = torch.cat([rows_o, rows_f]); cols = torch.cat([A_own.col.long(), A_far.col.long() + n])
+vals = torch.cat([A_own.val, A_far.val])
+order = torch.argsort(rows * (n + k) + cols)
+A_all = ops.Csr(rp.int(), cols[order].int(), vals[order], n + k)
+plan2 = D.HaloPlan(bounds=[0, n], rank=0, col_compact=A_all.col, send_rows=send_rows, send_counts=[k], recv_counts=[k], n_own=n)
+got2 = D.layer_halo(backend, A_all, X, Wt, True, plan2)
+table = torch.cat([H, H.index_select(0, send_rows)])
+assert torch.equal(got2, ops.spmm(A_all, table, relu=True))
+assert torch.allclose(got2.float(), want.float(), rtol=2e-3, atol=2e-3)
+got3 = D.layer_allgather(backend, A_own, X, Wt, True, [0, n])
+assert torch.equal(got3, ops.spmm(A_own, H, relu=True))
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl-self-ok")
+'''
+
+
+def test_exchanges_over_rccl_single_rank():
+    """The three exchanges on the real RCCL backend (`nccl`), in a one-rank world that sends rows to
+    itself -- the box has one GPU, RCCL refuses two ranks on it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", _RCCL_SELF, ROOT, str(29400 + os.getpid() % 500)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl-self-ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
