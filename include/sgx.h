@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 100
+#define SGX_VERSION 101
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -81,6 +81,41 @@ int sgx_plan_long_rows(const sgx_plan *plan);
 float sgx_plan_natural_utilization(const sgx_plan *plan);
 int sgx_plan_reordered(const sgx_plan *plan);
 
+/* ---- quantised layer of the SGRACE bitstream (SG.py:53-265, :570-667, :1645-1848) -------
+ * The reference quantises inside the device kernel from scale registers and states the arithmetic
+ * in its emulation branch (SG.py:570-667): features and adjacency values go to an unsigned w_qbits
+ * grid, weights and the attention vector to a signed one, each put back on a fractional grid
+ * (x_q / 2^(w_qbits-1)); H = X.W is divided by 2^scale_fea, clipped to +-(2^ib - 1)/2^ib and rounded
+ * to ib - 1 decimals (ib = internal_quantization); after aggregation and ReLU the result is
+ * multiplied by deq_o.  All of it in fp32 (dtype must be SGX_F32).  The fields are the registers of
+ * the GAT bitstream (SG.py:335-365, :476; demo/zcu104/gat_all_unsigned.hwh). */
+#define SGX_QUANT_ADJ_DONE 1   /* flags: values_adj already hold quantised values (graph cached by the host) */
+typedef struct sgx_quant {
+    int32_t qbits;              /* config.w_qbits: 8, 4, 2 or 1                                       */
+    int32_t scale_fea;          /* register scale_fea                                                 */
+    int32_t internal_bits;      /* register quantized_multiplier = internal_quantization (SG.py:476)  */
+    int32_t flags;
+    float   inv_scale_fea;      /* register quantization_scale_fea = 1 / f_s                          */
+    float   zero_fea;           /* f_z                                                                */
+    float   inv_scale_w;        /* register quantization_scale_w = 1 / w_s (also used for `attention`) */
+    float   zero_w;             /* w_z                                                                */
+    float   inv_scale_adj;      /* register quantization_scale_adj = 1 / a_s                          */
+    float   zero_adj;           /* a_z                                                                */
+    float   deq_factor;         /* register deq_factor = deq_o                                        */
+    float   reserved;
+    int64_t nnz_adj;            /* registers nnz_adj1..4 (SG.py:1205-1260): stored entries of A       */
+    int64_t nnz_fea;            /* registers nnz_fea1..4: stored entries of X (gemm_mode 0)           */
+} sgx_quant;
+
+/* The two rounding steps on their own (fp32, device pointers; out may alias x):
+ *   out = clip(round(inv_scale * x + zero), lo, hi) / 2^(qbits-1)   unsigned: lo = 0, hi = 2^qbits - 1
+ *                                                                   signed:   -+(2^(qbits-1) - 1)
+ *   qbits = 1: signed -> -0.5 / +0.5 by sign (SG.py:177-182), unsigned -> clip(round, 0, 1) / 2 (SG.py:184-189)
+ *   H = round_decimals(clip(H / 2^scale_fea, +-(2^ib - 1) / 2^ib), ib - 1), in place (SG.py:607-616) */
+int sgx_fake_quantize(int is_signed, int qbits, float inv_scale, float zero, int64_t n, const float *x,
+                      float *out, void *stream);
+int sgx_requantize(int n_rows, int n_feat, int64_t ld, float *H, int scale_fea, int internal_bits, void *stream);
+
 /* ---- the layer: replaces mmult_top / kernelmult1 (K.cpp:3762, :3969; KH:13-58) ------ */
 typedef struct sgx_layer_desc {
     /* AXI-Lite scalars of the reference, same names (K.cpp:3777-3790, MMN cell 13) */
@@ -100,7 +135,10 @@ typedef struct sgx_layer_desc {
     int32_t spmm_block;  /* SPMM_BLOCK of the reference (MM.h:188); only observable in
                             SGX_ACC_REF_HALF (it fixes the partial-sum lane of each element);
                             0 means 1                                                        */
-    int32_t reserved0;
+    int32_t gat_fill_dead_rows; /* gat_mode: what a row of A without a positive entry receives.
+                            1: the mean of all rows of Wh -- the reference's dense emulation (its masked
+                               row is constant, the softmax uniform over all N nodes, SG.py:638-641);
+                            0: zero.  Equal whenever every row has a positive entry (self loops)   */
 
     /* buffers (device) -- the m_axi ports of K.cpp:3792-3828; the reference's four
      * aliases per port (rowPtr_fea1..4 etc., main_float.cpp:880-887) collapse to one */
@@ -134,6 +172,9 @@ typedef struct sgx_layer_desc {
      * right after the aggregation stage (A.H or GAT).  NULL = not recorded. */
     void *ev_agg_begin;
     void *ev_agg_end;
+
+    /* optional: run the layer with the quantised arithmetic above (NULL = plain fp16/fp32 layer) */
+    const sgx_quant *quant;
 } sgx_layer_desc;
 
 size_t sgx_layer_workspace_bytes(const sgx_layer_desc *desc);
@@ -186,8 +227,10 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
 /* GAT aggregation on an already computed Wh (SG.py:309-314, :634-661), single head:
  *   e_ij = LeakyReLU_alpha(Wh_i.a1 + Wh_j.a2) for stored edges with values[e] > 0,
  *   alpha_ij = softmax_j(e_ij),  D_i = act(sum_j alpha_ij Wh_j).
- * s_scratch: 2*n_rows floats (the per-node scores Wh.a1, Wh.a2).  E/S optional [nnz] fp32. */
-int sgx_gat_aggregate(int dtype, int relu, int n_rows, int n_feat, float alpha,
+ * fill_dead_rows: see sgx_layer_desc.gat_fill_dead_rows.  s_scratch: sgx_gat_scratch_bytes() bytes
+ * (the per-node scores Wh.a1, Wh.a2 and the column-mean partials).  E/S optional [nnz] fp32. */
+size_t sgx_gat_scratch_bytes(int n_rows, int n_feat, int fill_dead_rows);
+int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_feat, float alpha,
                       const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                       const void *Wh, int64_t ldh, const void *attention,
                       void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream);

@@ -22,9 +22,10 @@ SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 SYMBOLS = [
     "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_natural_utilization",
     "sgx_plan_reordered",
+    "sgx_fake_quantize", "sgx_requantize",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
     "sgx_spmm_csr", "sgx_spmm_csr_acc", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
-    "sgx_gat_aggregate", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
+    "sgx_gat_aggregate", "sgx_gat_scratch_bytes", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
     "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear",
     "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_version", "sgx_status_string",
@@ -37,13 +38,29 @@ class SgxError(RuntimeError):
         super().__init__(f"{where}: {status_string(status)} (sgx_status {status})")
 
 
+SGX_QUANT_ADJ_DONE = 1
+
+
+class Quant(ctypes.Structure):
+    """struct sgx_quant -- field order and types must match include/sgx.h."""
+    _fields_ = [
+        ("qbits", ctypes.c_int32), ("scale_fea", ctypes.c_int32), ("internal_bits", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+        ("inv_scale_fea", ctypes.c_float), ("zero_fea", ctypes.c_float),
+        ("inv_scale_w", ctypes.c_float), ("zero_w", ctypes.c_float),
+        ("inv_scale_adj", ctypes.c_float), ("zero_adj", ctypes.c_float),
+        ("deq_factor", ctypes.c_float), ("reserved", ctypes.c_float),
+        ("nnz_adj", ctypes.c_int64), ("nnz_fea", ctypes.c_int64),
+    ]
+
+
 class LayerDesc(ctypes.Structure):
     """struct sgx_layer_desc -- field order and types must match include/sgx.h."""
     _fields_ = [
         ("gemm_mode", ctypes.c_int32), ("relu", ctypes.c_int32), ("gat_mode", ctypes.c_int32),
         ("N_adj", ctypes.c_int32), ("M_adj", ctypes.c_int32), ("M_fea", ctypes.c_int32),
         ("P_w", ctypes.c_int32), ("bias_count", ctypes.c_int32), ("dtype", ctypes.c_int32),
-        ("acc_mode", ctypes.c_int32), ("spmm_block", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("acc_mode", ctypes.c_int32), ("spmm_block", ctypes.c_int32), ("gat_fill_dead_rows", ctypes.c_int32),
         ("B", ctypes.c_void_p), ("D", ctypes.c_void_p),
         ("rowPtr_fea", ctypes.c_void_p), ("columnIndex_fea", ctypes.c_void_p), ("values_fea", ctypes.c_void_p),
         ("rowPtr_adj", ctypes.c_void_p), ("columnIndex_adj", ctypes.c_void_p), ("values_adj", ctypes.c_void_p),
@@ -52,6 +69,7 @@ class LayerDesc(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("plan_adj", ctypes.c_void_p), ("plan_fea", ctypes.c_void_p),
         ("ev_agg_begin", ctypes.c_void_p), ("ev_agg_end", ctypes.c_void_p),
+        ("quant", ctypes.POINTER(Quant)),
     ]
 
 
@@ -72,6 +90,10 @@ def _load():
     lib.sgx_plan_natural_utilization.restype = ctypes.c_float
     lib.sgx_plan_reordered.argtypes = [vp]
     lib.sgx_plan_reordered.restype = c_int
+    lib.sgx_fake_quantize.argtypes = [c_int, c_int, ctypes.c_float, ctypes.c_float, c_i64, vp, vp, vp]
+    lib.sgx_fake_quantize.restype = c_int
+    lib.sgx_requantize.argtypes = [c_int, c_int, c_i64, vp, c_int, c_int, vp]
+    lib.sgx_requantize.restype = c_int
     lib.sgx_layer_workspace_bytes.argtypes = [ctypes.POINTER(LayerDesc)]
     lib.sgx_layer_workspace_bytes.restype = sz
     lib.sgx_layer_forward.argtypes = [ctypes.POINTER(LayerDesc), vp]
@@ -91,7 +113,9 @@ def _load():
     lib.sgx_xw_sparse.restype = c_int
     lib.sgx_transpose.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp]
     lib.sgx_transpose.restype = c_int
-    lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
+    lib.sgx_gat_scratch_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sgx_gat_scratch_bytes.restype = sz
+    lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
                                       vp, c_i64, vp, vp, vp, vp]
     lib.sgx_gat_aggregate.restype = c_int
     lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]

@@ -5,9 +5,7 @@ that code written against `import config; config.acc = 1` keeps working:
     import sgracex1_amd.config as config
 
 Each flag is declared once in `_FLAGS` below with what it means HERE; the module then publishes
-them as plain module attributes.  Only the flags that reach the GPU hot path are live.  The
-quantisation switches of the SGRACE bitstream are accepted for source compatibility but must stay
-at their "off" values -- the int8/1-bit kernel is outside the fp16/fp32 path of this package.
+them as plain module attributes.  Only the flags that reach the GPU hot path are live.
 """
 import numpy as _np
 
@@ -28,10 +26,11 @@ _FLAGS = {
     "profiling": (0, "print per-layer host timings"),
     "show_max_min": (0, "print value ranges"),
     "min_output": (1, "quiet mode"),
-    # -- quantised bitstream: must stay off -------------------------------------------------------
-    "fake_quantization": (0, "emulate the int8 bitstream in torch: unsupported (layers raise if set)"),
-    "hardware_quantize": (0, "int8 bitstream quantiser"),
-    "w_qbits": (32, "weight bits of the quantised bitstream"),
+    # -- quantised bitstream (SG.py:570-667, :1645-1848; sgracex1_amd/quant.py) ------------------------
+    "fake_quantization": (0, "1 = layers use the quantised arithmetic of the SGRACE bitstream (fp32 tensors, "
+                             "w_qbits in {8, 4, 2, 1}); read by init_SGRACE and FPYNQ_GAT"),
+    "hardware_quantize": (0, "the bitstream's own quantiser: same arithmetic here as fake_quantization"),
+    "w_qbits": (32, "operand bits of the quantised layer; 32 = not quantised"),
     # -- buffer capacities of the PYNQ allocation step (informational here) ----------------------
     "N_adj": (20480, "max nodes"), "M_adj": (20480, "max nodes"), "M_fea": (2048, "max input features"),
     "NNZ_adj": (1_000_000, "max adjacency non-zeros"), "NNZ_fea": (4_000_000, "max feature non-zeros"),

@@ -8,8 +8,11 @@
 // of LPR lanes per row (the same sblock layout as spmm_csr.hip), pass 1 = online max / sum over
 // the 4-byte scores, pass 2 = the 16-byte row gathers weighted by alpha_ij.  The hardware's
 // per-edge side outputs E (pre-softmax) and S (softmax) (SG.py:500-502) are optional.
-// Rows with no positive edge produce 0 (never reached from the reference's call path: sym_norm2
-// adds self loops, SG.py:42).
+// Rows with no positive edge: the emulation's masked dense row is constant (-9e15 everywhere,
+// SG.py:638-641), its softmax uniform over all N nodes, so the row receives the mean of all rows
+// of Wh.  sym_norm2's self loops (SG.py:42) keep the plain path away from this case, the quantised
+// adjacency does not (small values round to 0).  `fill_dead_rows` selects that result (one more
+// pass over Wh for the column means); without it such rows produce 0.
 #include "sgx_device.h"
 
 #include <math.h>
@@ -69,7 +72,8 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
-    T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store)
+    T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
+    const float *__restrict__ fill)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -98,6 +102,8 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
         softmax_merge(m, l, m2, l2);
     }
     const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+    const bool dead = live && !(l > 0.0f) && fill != nullptr;
+    const float uniform = 1.0f / (float)n_rows;
 
     // pass 2: weighted gather of the neighbour rows
     for (int c0 = 0; c0 < n_feat; c0 += TILE) {
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
                 if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(x - m) * inv_l;
                 if (c0 == 0) {
                     if (E) E[idx] = x;
-                    if (S) S[idx] = p;
+                    if (S) S[idx] = dead ? uniform : p;
                 }
             }
             const int n = e1 - base;
@@ -135,6 +141,10 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
         }
         if (live && col0 < n_feat) {
             T out[VEC];
+            if (dead) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = (col0 + i < n_feat) ? fill[col0 + i] : 0.0f;
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 T v = Elem<T>::from_f32(acc[i]);
@@ -152,6 +162,33 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     }
 }
 
+// Column means of Wh in two fixed-order stages: slab sums, then the slabs added in order.
+constexpr int kMeanSlabs = 512;
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void col_sum_slab_kernel(int n_rows, int n_feat, const T *__restrict__ Wh, int64_t ldh,
+                                                             float *__restrict__ partial)
+{
+    const int rows_per = (n_rows + kMeanSlabs - 1) / kMeanSlabs;
+    const int r0 = blockIdx.x * rows_per;
+    const int r1 = r0 + rows_per < n_rows ? r0 + rows_per : n_rows;
+    for (int j = threadIdx.x; j < n_feat; j += kBlock) {
+        float s = 0.0f;
+        for (int r = r0; r < r1; ++r) s += Elem<T>::to_f32(Wh[(int64_t)r * ldh + j]);
+        partial[(int64_t)blockIdx.x * n_feat + j] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void col_mean_finish_kernel(int n_rows, int n_feat, const float *__restrict__ partial,
+                                                                float *__restrict__ mean)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_feat) return;
+    float s = 0.0f;
+    for (int b = 0; b < kMeanSlabs; ++b) s += partial[(int64_t)b * n_feat + j];
+    mean[j] = s / (float)n_rows;
+}
+
 struct GatArgs {
     int relu, n_rows, n_feat;
     float alpha;
@@ -161,6 +198,7 @@ struct GatArgs {
     unsigned h_bytes, ld_bytes;
     void *D;
     float *E, *S, *s;
+    const float *fill;
     int vec_ok, vec_store;
     hipStream_t stream;
 };
@@ -176,7 +214,7 @@ int gat_launch_one(const GatArgs &a)
     SGX_LAUNCH_CHECK();
     hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_feat,
                        a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
-                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store);
+                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -197,7 +235,15 @@ int gat_launch_lpr(const GatArgs &a, int lpr)
 
 }  // namespace
 
-extern "C" int sgx_gat_aggregate(int dtype, int relu, int n_rows, int n_feat, float alpha,
+extern "C" size_t sgx_gat_scratch_bytes(int n_rows, int n_feat, int fill_dead_rows)
+{
+    if (n_rows < 0 || n_feat < 1) return 0;
+    size_t floats = (size_t)2 * n_rows;
+    if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
+    return sgx_align_up(floats * sizeof(float), 256);
+}
+
+extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_feat, float alpha,
                                  const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                                  const void *Wh, int64_t ldh, const void *attention,
                                  void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream)
@@ -215,6 +261,21 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int n_rows, int n_feat, fl
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
+    a.fill = nullptr;
+    if (fill_dead_rows) {
+        float *partial = s_scratch + (size_t)2 * n_rows, *mean = partial + (size_t)kMeanSlabs * n_feat;
+        if (dtype == SGX_F16)
+            hipLaunchKernelGGL(col_sum_slab_kernel<f16>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_rows, n_feat,
+                               (const f16 *)Wh, ldh, partial);
+        else
+            hipLaunchKernelGGL(col_sum_slab_kernel<float>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_rows, n_feat,
+                               (const float *)Wh, ldh, partial);
+        SGX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(col_mean_finish_kernel, dim3((n_feat + kBlock - 1) / kBlock), dim3(kBlock), 0, a.stream, n_rows,
+                           n_feat, partial, mean);
+        SGX_LAUNCH_CHECK();
+        a.fill = mean;
+    }
     a.vec_ok = ((uintptr_t)Wh % 16 == 0) && ((ldh * es) % 16 == 0);
     a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
     const int per16 = (int)(16 / es);

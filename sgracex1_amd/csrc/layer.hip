@@ -14,6 +14,8 @@ struct Carve {
     size_t w_off, w_bytes;        // W  [M_fea][ldh]  (row-major copy of B, gemm_mode 0 only)
     size_t s_off, s_bytes;        // split-row partial sums (max of both stages)
     size_t g_off, g_bytes;        // GAT per-node scores, 2*N floats
+    size_t q_off, q_bytes;        // quantised layer: copies of B, X (values), A (values), attention
+    size_t qb, qx, qa, qt;        //   their offsets inside the q block
     size_t total;
 };
 
@@ -28,7 +30,17 @@ Carve carve(const sgx_layer_desc *d)
     size_t s1 = sgx_spmm_scratch_bytes(d->plan_adj, d->P_w);
     size_t s2 = d->gemm_mode == 0 ? sgx_spmm_scratch_bytes(d->plan_fea, d->P_w) : 0;
     c.s_off = off; c.s_bytes = s1 > s2 ? s1 : s2; off += c.s_bytes;
-    c.g_off = off; c.g_bytes = d->gat_mode ? sgx_align_up((size_t)d->N_adj * 2 * sizeof(float), 256) : 0; off += c.g_bytes;
+    c.g_off = off; c.g_bytes = d->gat_mode ? sgx_gat_scratch_bytes(d->N_adj, d->P_w, d->gat_fill_dead_rows) : 0; off += c.g_bytes;
+    c.q_off = off; c.q_bytes = 0; c.qb = c.qx = c.qa = c.qt = 0;
+    if (d->quant) {
+        const sgx_quant *q = d->quant;
+        size_t o = 0;
+        c.qb = o; o += sgx_align_up((size_t)d->P_w * d->M_fea * 4, 256);
+        c.qx = o; o += sgx_align_up((d->gemm_mode == 0 ? (size_t)q->nnz_fea : (size_t)d->M_adj * d->M_fea) * 4, 256);
+        c.qa = o; o += (q->flags & SGX_QUANT_ADJ_DONE) ? 0 : sgx_align_up((size_t)q->nnz_adj * 4, 256);
+        c.qt = o; o += d->gat_mode ? sgx_align_up((size_t)2 * d->P_w * 4, 256) : 0;
+        c.q_bytes = o; off += o;
+    }
     c.total = off;
     return c;
 }
@@ -39,6 +51,17 @@ int check_desc(const sgx_layer_desc *d)
     if (d->N_adj < 0 || d->M_adj < 0 || d->M_fea < 1 || d->P_w < 1) return SGX_ERR_SHAPE;
     if (d->dtype != SGX_F16 && d->dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
     if (d->gemm_mode != 0 && d->gemm_mode != 1) return SGX_ERR_UNSUPPORTED;   // 2 = backward offload, not in the public HLS
+    if (d->quant) {
+        const sgx_quant *q = d->quant;
+        if (d->dtype != SGX_F32 || d->acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;   // SG.py:1545: float32 buffers
+        if (q->qbits < 1 || q->qbits > 16 || q->scale_fea < 0 || q->scale_fea > 30 || q->internal_bits < 1 ||
+            q->internal_bits > 30)
+            return SGX_ERR_UNSUPPORTED;
+        if (q->nnz_adj < 0 || q->nnz_fea < 0) return SGX_ERR_SHAPE;
+        // entries that are not stored must stay zero after quantisation (a_min = f_min = 0 in every
+        // table of SG.py:1298-1537): a non-zero zero point would turn the CSR operands dense
+        if (q->zero_adj != 0.0f || (d->gemm_mode == 0 && q->zero_fea != 0.0f)) return SGX_ERR_UNSUPPORTED;
+    }
     return SGX_OK;
 }
 
@@ -82,31 +105,67 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     void *scratch = c.s_bytes ? ws + c.s_off : nullptr;
     const int64_t ldh = sgx_ldh(d->dtype, d->P_w);
 
+    // quantised layer: the operands are replaced by their quantised copies (SG.py:574, :593, :624-626)
+    const void *B = d->B, *values_fea = d->values_fea, *values_adj = d->values_adj, *attention = d->attention;
+    const sgx_quant *q = d->quant;
+    if (q) {
+        if (!d->values_adj) return SGX_ERR_NULL;
+        float *qbase = (float *)(ws + c.q_off);
+        float *Bq = (float *)((char *)qbase + c.qb), *Xq = (float *)((char *)qbase + c.qx);
+        rc = sgx_fake_quantize(1, q->qbits, q->inv_scale_w, q->zero_w, (int64_t)d->P_w * d->M_fea, (const float *)d->B, Bq, s);
+        if (rc != SGX_OK) return rc;
+        const int64_t nx = d->gemm_mode == 0 ? q->nnz_fea : (int64_t)d->M_adj * d->M_fea;
+        rc = sgx_fake_quantize(0, q->qbits, q->inv_scale_fea, q->zero_fea, nx, (const float *)d->values_fea, Xq, s);
+        if (rc != SGX_OK) return rc;
+        B = Bq; values_fea = Xq;
+        if (!(q->flags & SGX_QUANT_ADJ_DONE)) {
+            float *Aq = (float *)((char *)qbase + c.qa);
+            rc = sgx_fake_quantize(0, q->qbits, q->inv_scale_adj, q->zero_adj, q->nnz_adj, (const float *)d->values_adj, Aq, s);
+            if (rc != SGX_OK) return rc;
+            values_adj = Aq;
+        }
+        if (d->gat_mode) {
+            if (!d->attention) return SGX_ERR_NULL;
+            float *Tq = (float *)((char *)qbase + c.qt);
+            rc = sgx_fake_quantize(1, q->qbits, q->inv_scale_w, q->zero_w, (int64_t)2 * d->P_w, (const float *)d->attention, Tq, s);
+            if (rc != SGX_OK) return rc;
+            attention = Tq;
+        }
+    }
+
     // stage 1: H = X . W          (loop_fea, K.cpp:2932)
     if (d->gemm_mode == 0) {
-        rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, d->B, d->M_fea, W, ldh, s);      // B [P][M] -> W [M][ldh]
+        rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, B, d->M_fea, W, ldh, s);         // B [P][M] -> W [M][ldh]
         if (rc != SGX_OK) return rc;
         rc = sgx_xw_sparse(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
-                           d->columnIndex_fea, d->values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s);
+                           d->columnIndex_fea, values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s);
     } else {
-        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->values_fea, d->M_fea, d->B, d->M_fea,
+        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
                           H, ldh, s);
     }
     if (rc != SGX_OK) return rc;
+    if (q) {                                                                            // SG.py:603-616
+        rc = sgx_requantize(d->M_adj, d->P_w, ldh, (float *)H, q->scale_fea, q->internal_bits, s);
+        if (rc != SGX_OK) return rc;
+    }
 
     // stage 2: D = act(A . H)     (loop_adj, K.cpp:3339) or the edge-softmax aggregate (SG.py:634-661)
     if (d->ev_agg_begin) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_begin, s));
     if (d->gat_mode) {
-        if (!d->attention) return SGX_ERR_NULL;
-        rc = sgx_gat_aggregate(d->dtype, d->relu, d->N_adj, d->P_w, d->alpha, d->rowPtr_adj, d->columnIndex_adj,
-                               d->values_adj, H, ldh, d->attention, d->D, d->P_w, (float *)d->E, (float *)d->S,
+        if (!attention) return SGX_ERR_NULL;
+        rc = sgx_gat_aggregate(d->dtype, d->relu, d->gat_fill_dead_rows, d->N_adj, d->P_w, d->alpha, d->rowPtr_adj, d->columnIndex_adj,
+                               values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S,
                                (float *)(ws + c.g_off), s);
     } else {
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,
-                             d->rowPtr_adj, d->columnIndex_adj, d->values_adj, H, ldh, d->D, d->P_w, d->plan_adj,
+                             d->rowPtr_adj, d->columnIndex_adj, values_adj, H, ldh, d->D, d->P_w, d->plan_adj,
                              scratch, c.s_bytes, s);
     }
     if (rc != SGX_OK) return rc;
+    if (q) {                                                                            // SG.py:666-667
+        rc = sgx_scale_f32((int64_t)d->N_adj * d->P_w, (float *)d->D, q->deq_factor, s);
+        if (rc != SGX_OK) return rc;
+    }
     if (d->ev_agg_end) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_end, s));
     return SGX_OK;
 }

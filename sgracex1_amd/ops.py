@@ -105,6 +105,28 @@ class Csr:
         self.n_rows = rowptr.numel() - 1
         self.n_cols = int(n_cols)
         self._plan = plan
+        self._dead_rows = None
+        self._quantized = {}
+
+    @property
+    def has_dead_rows(self):
+        """True when some row holds no positive value -- the rows the GAT mask `adj > 0` (SG.py:640)
+        leaves without a neighbour.  One device->host sync, once per matrix."""
+        if self._dead_rows is None:
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            row = torch.repeat_interleave(torch.arange(self.n_rows, device=self.val.device), deg)
+            live = torch.zeros(self.n_rows, dtype=torch.int32, device=self.val.device)
+            live.index_add_(0, row, (self.val > 0).to(torch.int32))
+            self._dead_rows = bool((live == 0).any().item())
+        return self._dead_rows
+
+    def quantized(self, qc):
+        """The adjacency on the unsigned w_qbits grid (SG.py:626), quantised once per graph and constants."""
+        key = (qc.w_qbits, qc.a_s, qc.a_z)
+        if key not in self._quantized:
+            self._quantized[key] = Csr(self.rowptr, self.col, fake_quantize(self.val, 0, qc.w_qbits, qc.a_s, qc.a_z),
+                                       self.n_cols, self._plan)
+        return self._quantized[key]
 
     @property
     def nnz(self):
@@ -232,12 +254,17 @@ def transpose(x, ldo=None):
 
 
 def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
-                  acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None):
+                  acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None,
+                  quant=None, adj_quantized=False, cache_quantized_adj=True):
     """One fused layer  D = act(A . (X . W))  through sgx_layer_forward.
 
     adj : Csr [N, M_adj];  fea : Csr [M_adj, M_fea] (gemm_mode 0) or dense tensor (gemm_mode 1);
     Wt  : [P, M_fea] -- the weights TRANSPOSED, what the reference writes into B_buffer.
     Returns D [N, P] (and (E, S) per-edge tensors when want_edge_outputs with GAT).
+    quant: a quant.QuantConstants -- run the layer with the quantised arithmetic of the SGRACE
+    bitstream (fp32 tensors only); adj_quantized: adj.val already went through the quantiser;
+    cache_quantized_adj: quantise the adjacency once per graph on the host side instead of inside
+    every call (always done for GAT, whose mask decides how rows without a live edge are treated).
     """
     _dev(Wt, "Wt")
     code = dtype_code(Wt.dtype)
@@ -249,6 +276,8 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     d.bias_count, d.dtype, d.acc_mode, d.spmm_block = bias_count, code, acc_mode, spmm_block
     if adj.val.dtype != Wt.dtype:
         raise TypeError("adjacency, features and weights must share one element type (MM.h:129-139)")
+    if quant is not None and Wt.dtype != torch.float32:
+        raise TypeError("the quantised layer works on float32 buffers (SG.py:1545)")
     if gemm_mode == 0:
         if fea.val.dtype != Wt.dtype or fea.n_rows != adj.n_cols or fea.n_cols != M_fea:
             raise ValueError("feature CSR does not match adjacency / weights")
@@ -261,6 +290,10 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
         if fea.dtype != Wt.dtype or fea.shape != (adj.n_cols, M_fea):
             raise ValueError(f"dense features must be [{adj.n_cols}, {M_fea}] {Wt.dtype}")
         d.values_fea = fea.data_ptr()
+    if quant is not None and not adj_quantized and (cache_quantized_adj or gat_attention is not None):
+        adj, adj_quantized = adj.quantized(quant), True
+    if gat_attention is not None:
+        d.gat_fill_dead_rows = int(adj.has_dead_rows)
     d.rowPtr_adj, d.columnIndex_adj, d.values_adj = adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr()
     if use_plan and adj.wants_plan:
         d.plan_adj = adj.plan.handle
@@ -280,11 +313,36 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
             d.E, d.S = E.data_ptr(), S.data_ptr()
     if agg_events is not None:          # (begin, end) hipEvent_t handles, see hipevents.py
         d.ev_agg_begin, d.ev_agg_end = agg_events
+    if quant is not None:
+        qs = quant.as_struct(nnz_adj=adj.nnz, nnz_fea=fea.nnz if gemm_mode == 0 else 0, adj_done=adj_quantized)
+        d.quant = ctypes.pointer(qs)
     nbytes = lib.sgx_layer_workspace_bytes(ctypes.byref(d))
     ws = _workspace(Wt.device, nbytes)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib.sgx_layer_forward(ctypes.byref(d), _stream()), "sgx_layer_forward")
     return (out, E, S) if want_edge_outputs else out
+
+
+def fake_quantize(x, signed, qbits, scale, zero, out=None):
+    """quantization_fbits (signed) / quantization_ufbits (SG.py:238-265) of an fp32 tensor on the device."""
+    _dev(x, "x")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError("fake_quantize works on contiguous float32 tensors (SG.py:1545)")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.sgx_fake_quantize(int(bool(signed)), int(qbits), float(1 / scale), float(zero), x.numel(), _ptr(x), _ptr(out),
+                                _stream()), "sgx_fake_quantize")
+    return out
+
+
+def requantize_(H, scale_fea, internal_bits):
+    """H <- round_decimals(clip(H / 2^scale_fea), internal_bits - 1) in place (SG.py:607-616)."""
+    _dev2d(H, "H")
+    if H.dtype != torch.float32:
+        raise TypeError("requantize_ works on float32")
+    check(lib.sgx_requantize(H.shape[0], H.shape[1], H.stride(0), _ptr(H), int(scale_fea), int(internal_bits), _stream()),
+          "sgx_requantize")
+    return H
 
 
 def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False):
@@ -297,8 +355,9 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
     if want_edge_outputs:
         E = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
         S = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
-    s = torch.empty(2 * N, dtype=torch.float32, device=Wh.device)
-    check(lib.sgx_gat_aggregate(code, int(bool(relu)), adj.n_rows, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
+    fill = int(adj.has_dead_rows)
+    s = torch.empty(lib.sgx_gat_scratch_bytes(adj.n_rows, F, fill) // 4, dtype=torch.float32, device=Wh.device)
+    check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
                                 _ptr(E), _ptr(S), _ptr(s), _stream()), "sgx_gat_aggregate")
     return (out, E, S) if want_edge_outputs else out

@@ -171,8 +171,33 @@ class IP:
         self.alpha = 0.2
         self.register_map = RegisterMap(self)
 
+    # -- quantised bitstream: constants as the reference programs them (SG.py:335-365, :476, :1745-1838)
+    _BETA_QU_BITS = {255: 8, 15: 4, 2: 2, 1: 1}
+
+    def quant_from_registers(self):
+        """The sgx_quant constants held in the register map, or None when the quantiser registers were
+        never written (plain fp16/fp32 layer).  The scale registers hold float32 bit patterns."""
+        from .quant import QuantConstants
+        rm, regs = self.register_map, self.register_map._regs
+        need = ("quantization_scale_fea", "quantization_scale_w", "quantization_scale_adj", "deq_factor", "scale_fea",
+                "quantized_multiplier", "beta_qu")
+        if not all(r in regs for r in need):
+            return None
+        bits = self._BETA_QU_BITS.get(int(rm.beta_qu))
+        if bits is None:
+            raise ValueError(f"register beta_qu = {rm.beta_qu}: expected one of {sorted(self._BETA_QU_BITS)}")
+
+        def f32(reg):
+            return float(np.asarray(int(getattr(rm, reg)), dtype=np.int64).astype(np.uint32).view(np.float32))
+
+        return QuantConstants(w_qbits=bits, w_s=1 / f32("quantization_scale_w"), w_z=0,
+                              a_s=1 / f32("quantization_scale_adj"), a_z=0, f_s=1 / f32("quantization_scale_fea"), f_z=0,
+                              scale_fea=int(rm.scale_fea), internal_quantization=int(rm.quantized_multiplier),
+                              deq_o=f32("deq_factor"))
+
     # -- fast path: everything already in HBM ------------------------------------------------
-    def run_layer(self, adj, fea, Wt, attention=None, want_edge_outputs=False, out=None):
+    def run_layer(self, adj, fea, Wt, attention=None, want_edge_outputs=False, out=None, quant=None,
+                  adj_quantized=False):
         """One layer with the flags currently in the register map (relu, gat_mode; gemm_mode is
         implied by the type of `fea` and checked against the register)."""
         from . import ops
@@ -184,7 +209,8 @@ class IP:
         rm.N_adj, rm.M_adj, rm.M_fea, rm.P_w = adj.n_rows, adj.n_cols, Wt.shape[1], Wt.shape[0]
         gat = attention if int(rm.gat_mode) else None
         return ops.layer_forward(adj, fea, Wt, relu=int(rm.relu), gat_attention=gat, alpha=self.alpha,
-                                 want_edge_outputs=want_edge_outputs, bias_count=int(rm.bias_count), out=out)
+                                 want_edge_outputs=want_edge_outputs, bias_count=int(rm.bias_count), out=out,
+                                 quant=quant, adj_quantized=adj_quantized)
 
     # -- compat path: host buffers behind fake physical addresses ------------------------------
     def _start(self):
@@ -238,7 +264,8 @@ class IP:
             att = up(view("ate_m_offset_1", 2 * P), tdt)
         want_es = bool(int(rm.gat_mode)) and "E1_offset_1" in rm._regs and "S1_offset_1" in rm._regs
         res = ops.layer_forward(adj, fea, Wt, relu=int(rm.relu), gat_attention=att, alpha=self.alpha,
-                                want_edge_outputs=want_es, bias_count=int(rm.bias_count))
+                                want_edge_outputs=want_es, bias_count=int(rm.bias_count),
+                                quant=self.quant_from_registers())
         if int(rm.bias_count) > 0:
             return                                   # K.cpp:3876-3889: nothing is written
         out = res[0] if want_es else res

@@ -11,9 +11,14 @@
 
 `config.acc == 1` runs the layer on the GPU through the C ABI (GCN aggregate or single-head GAT
 edge softmax, selected by `compute_attention` -> register gat_mode); `config.acc == 0` is the
-reference's dense torch emulation (SG.py:563-681) kept as the parity twin.  The quantisation
-machinery of the SGRACE bitstream (SG.py:53-265, :570-616, :1645-1848) is not part of this path:
-`config.fake_quantization` must be 0.
+reference's dense torch emulation (SG.py:563-681) kept as the parity twin.
+
+Quantised bitstream (SG.py:53-265, :570-667, :1645-1848): with `config.w_qbits` in {8, 4, 2, 1} and
+`config.fake_quantization == 1` (or `config.hardware_quantize == 1`), `init_SGRACE` derives the
+constants (quant.py) and the layer runs with the quantised arithmetic -- on the GPU kernels for
+`acc == 1` (the registers scale_fea, deq_factor, quantization_scale_*, quantized_multiplier are
+programmed as the reference does, alternating between the layer-1 and layer-2 sets), in the dense
+emulation for `acc == 0`.  The backward pass uses the unquantised operands, as in the reference.
 
 Backward mirrors SG.py:884-1126 (the `accb == 0` branch) on the edge list instead of dense
 N x N matrices: grad_input = P @ (g @ W^T), grad_weights = X^T @ (P @ g) with P = the attention
@@ -26,11 +31,33 @@ from torch.nn import LeakyReLU, init
 from torch.nn.modules.module import Module
 from torch.nn.parameter import Parameter
 
-from . import config, ops
+import numpy as np
+
+from . import config, ops, quant
 from .molecule_gcn import RPYNQ  # noqa: F401  (same Function in both reference files)
 from .pyg_lite import add_remaining_self_loops, sort_edge_index
 
 my_ip = None
+quant_constants = None        # set by init_SGRACE when the quantised path is selected
+layern = 1                    # SG.py:327-359: the hardware path alternates two constant sets
+
+
+def _quantised():
+    return bool(config.fake_quantization) or bool(config.hardware_quantize)
+
+
+def _f32_bits(x):
+    return np.asarray(x, dtype=np.float32).view(np.int32).item()
+
+
+def _program_quant_registers(rm, qc):
+    """SG.py:334-365, :476: what FPYNQ_GAT.forward writes before AP_START."""
+    rm.scale_fea = qc.scale_fea
+    rm.deq_factor = _f32_bits(qc.deq_o)
+    rm.quantization_scale_fea = _f32_bits(1 / qc.f_s)
+    rm.quantization_scale_w = _f32_bits(1 / qc.w_s)
+    rm.quantization_scale_adj = _f32_bits(1 / qc.a_s)
+    rm.quantized_multiplier = qc.internal_quantization
 
 
 def _torch_dtype():
@@ -60,15 +87,41 @@ def _edge_csr(adj, edge_index, norm, n, dtype):
     return ops.Csr.from_coo(row, edge_index[1].to(torch.int32).contiguous(), norm.to(dtype).contiguous(), n, n)
 
 
+def _fq_signed(x, s, z, qbits):
+    """quantization_fbits (SG.py:238-251)."""
+    t = 1 / s * x + z
+    if qbits == 1:
+        return torch.where(t < 0, torch.full_like(t, -0.5), torch.full_like(t, 0.5))
+    lim = 2 ** (qbits - 1) - 1
+    return torch.clip(torch.round(t), min=-lim, max=lim) / (2 ** (qbits - 1))
+
+
+def _fq_unsigned(x, s, z, qbits):
+    """quantization_ufbits (SG.py:253-265)."""
+    q = torch.clip(torch.round(1 / s * x + z), min=0, max=2 ** qbits - 1)
+    return q / 2 if qbits == 1 else q / (2 ** (qbits - 1))
+
+
 class FPYNQ_GAT(torch.autograd.Function):
     @staticmethod
     def forward(ctx, my_ip, self, adj, nnz_adj, input, weights, attention, out_features, dropout, relu):
         ctx.nheads, ctx.alpha, ctx.relu = self.nheads, self.alpha, relu
         ctx.gat = int(config.compute_attention)
-        if config.fake_quantization:
-            raise NotImplementedError("the quantised SGRACE path is outside this package (set config.fake_quantization = 0)")
+        qc = None
+        if _quantised():
+            if quant_constants is None:
+                raise RuntimeError("config.fake_quantization is set: call init_SGRACE() with config.w_qbits in {8, 4, 2, 1}")
+            qc = quant_constants
         if config.acc == 1:
             dt = _torch_dtype()
+            if qc is not None:
+                global layern
+                if dt != torch.float32:
+                    raise TypeError("the quantised layer works on float32 buffers (SG.py:1545)")
+                if layern == 2:
+                    qc = qc.second_layer()
+                layern = 2 if layern == 1 else 1
+                _program_quant_registers(my_ip.register_map, qc)
             rm = my_ip.register_map
             A = self._csr if isinstance(adj, torch.Tensor) else adj
             A = A.to(dt)
@@ -81,17 +134,27 @@ class FPYNQ_GAT(torch.autograd.Function):
             my_ip.alpha = self.alpha
             if ctx.gat:
                 out, E, S = my_ip.run_layer(A, fea, Wt, attention=attention.detach().to(dt).reshape(-1).contiguous(),
-                                            want_edge_outputs=True)
+                                            want_edge_outputs=True, quant=qc)
             else:
-                out, E, S = my_ip.run_layer(A, fea, Wt), None, None
+                out, E, S = my_ip.run_layer(A, fea, Wt, quant=qc), None, None
             ctx.csr = A
             ctx.save_for_backward(input, weights, out, *([E, S] if ctx.gat else []))
             return out.float()                                            # SG.py:543 `.float()`
 
         # ---- no accelerator: the dense emulation of SG.py:563-681 --------------------------------
         input = input.float()
-        Wh = torch.mm(input, weights)
-        adj_d = adj.to_dense()
+        input_q, weights_q, adj_d = input, weights, adj.to_dense()
+        if qc is not None:                                                # SG.py:570-626
+            input_q = _fq_unsigned(input, qc.f_s, qc.f_z, qc.w_qbits)
+            weights_q = _fq_signed(weights, qc.w_s, qc.w_z, qc.w_qbits)
+        Wh = torch.mm(input_q, weights_q)
+        if qc is not None:
+            iq = qc.internal_quantization
+            Wh = Wh / (2 ** qc.scale_fea)
+            Wh = torch.clip(Wh, min=-(2 ** iq - 1) / (2 ** iq), max=(2 ** iq - 1) / (2 ** iq))
+            Wh = torch.round(Wh, decimals=iq - 1)
+            attention = _fq_signed(attention, qc.w_s, qc.w_z, qc.w_qbits)
+            adj_d = _fq_unsigned(adj_d, qc.a_s, qc.a_z, qc.w_qbits)
         Wh1 = torch.matmul(Wh, attention[:out_features, :])
         Wh2 = torch.matmul(Wh, attention[out_features:, :])
         e = self.leakyrelu(Wh1 + Wh2.T)
@@ -103,6 +166,8 @@ class FPYNQ_GAT(torch.autograd.Function):
             output_cpu = torch.matmul(adj_d, Wh)
         if relu == 1:
             output_cpu = torch.where(output_cpu > 0, output_cpu, torch.zeros_like(output_cpu))
+        if qc is not None:
+            output_cpu = output_cpu * qc.deq_o                            # SG.py:666-667
         ctx.csr = None
         ctx.save_for_backward(input, weights, output_cpu, e, attentions if ctx.gat else adj_d, adj_d)
         return output_cpu
@@ -216,9 +281,14 @@ class GATConv_SGRACE(Module):
 
 def init_SGRACE(device=None):
     """SG.py:1271: opens the overlay and publishes the IP handle the layers use."""
-    global my_ip
+    global my_ip, quant_constants, layern
+    layern = 1
+    quant_constants = quant.constants(config.w_qbits) if _quantised() else None
     if config.acc == 1:
         from .pynq_shim import Overlay
         ol = Overlay("gat_all_unsigned.bit", device=device or config.device)
         my_ip = ol.mmult_top_0
+        if quant_constants is not None:          # SG.py:1745-1839: f_align is the hardware's input alignment, unused here
+            my_ip.register_map.beta_qu = {8: 255, 4: 15, 2: 2, 1: 1}[config.w_qbits]
+            my_ip.register_map.f_align = {8: 0, 4: 4, 2: 6, 1: 7}[config.w_qbits]
     return my_ip

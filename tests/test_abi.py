@@ -43,6 +43,8 @@ def test_header_compiles_as_c_and_struct_layout_matches(L, tmp_path):
         "int main(void){\n"
         ' printf("%zu\\n", sizeof(sgx_layer_desc));\n'
         + "".join(f' printf("{name} %zu\\n", offsetof(sgx_layer_desc, {name}));\n' for name, _ in L.LayerDesc._fields_)
+        + ' printf("quant_struct %zu\\n", sizeof(sgx_quant));\n'
+        + "".join(f' printf("q.{name} %zu\\n", offsetof(sgx_quant, {name}));\n' for name, _ in L.Quant._fields_)
         + " return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
@@ -52,11 +54,16 @@ def test_header_compiles_as_c_and_struct_layout_matches(L, tmp_path):
     for ln in lines[1:]:
         if ln:
             name, off = ln.split()
-            assert getattr(L.LayerDesc, name).offset == int(off), name
+            if name == "quant_struct":
+                assert ctypes.sizeof(L.Quant) == int(off)
+            elif name.startswith("q."):
+                assert getattr(L.Quant, name[2:]).offset == int(off), name
+            else:
+                assert getattr(L.LayerDesc, name).offset == int(off), name
 
 
 def test_version_and_status_strings(L):
-    assert L.lib.sgx_version() == 100
+    assert L.lib.sgx_version() == 101
     assert L.status_string(0) == "ok"
     for code in range(-7, 0):
         assert L.status_string(code) != "unknown status"
@@ -85,6 +92,22 @@ def test_argument_checks_need_no_gpu(L):
     assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 8, None, None, None, None, 8, None, 8, None, None, 0, None) == -1
     assert L.lib.sgx_xw_dense(0, 0, 1, 4, 0, 8, None, 8, None, 8, None, 8, None) == -2
     assert L.lib.sgx_transpose(0, 4, 4, None, 4, None, 4, None) == -1
+    # quantised layer: fp32 only, zero points of the CSR operands must be 0, bit widths bounded
+    q = L.Quant()
+    q.qbits, q.scale_fea, q.internal_bits = 8, 4, 16
+    d.quant = ctypes.pointer(q)
+    assert L.lib.sgx_layer_workspace_bytes(ctypes.byref(d)) == 0           # dtype F16 with quant
+    d.dtype = 1
+    q.nnz_adj = 100
+    assert L.lib.sgx_layer_workspace_bytes(ctypes.byref(d)) >= need + 8 * 4 * 4 + 10 * 4 * 4 + 400
+    q.zero_adj = 1.0
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3
+    q.zero_adj, q.qbits = 0.0, 40
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3
+    assert L.lib.sgx_fake_quantize(1, 8, 1.0, 0.0, -1, None, None, None) == -2
+    assert L.lib.sgx_fake_quantize(1, 0, 1.0, 0.0, 4, None, None, None) == -3
+    assert L.lib.sgx_fake_quantize(1, 8, 1.0, 0.0, 4, None, None, None) == -1
+    assert L.lib.sgx_requantize(4, 8, 4, None, 4, 16, None) == -2
 
 
 def test_product_path_has_no_oracle_or_cpu_fallback():

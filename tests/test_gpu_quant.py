@@ -1,0 +1,209 @@
+"""The quantised layer on the GPU (sgx_fake_quantize, sgx_requantize, sgx_layer_forward with a
+sgx_quant block) against the CPU restatement of SG.py:565-667 (oracle/quant_oracle.py).  The two
+rounding kernels are compared bit for bit; the layer within the fp32 band of the plain fp32 layer
+(sums are formed in another order than torch.mm / torch.matmul).  Parity unpinned -- see the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import quant_oracle as QO
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda")
+
+
+def _points(scale, n, seed):
+    """random values plus every half-way point of the grid (round-half-even) and out-of-range ones"""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, generator=g) * 2.6 - 1.3) * scale * 300
+    k = torch.arange(-300, 300, dtype=torch.float64)
+    ties = ((k + 0.5) * scale).float()
+    return torch.cat([x, ties, torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e30, -1e30])])
+
+
+@pytest.mark.parametrize("bits", [8, 4, 2, 1])
+@pytest.mark.parametrize("signed", [0, 1])
+def test_fake_quantize_bit_exact(bits, signed):
+    from sgracex1_amd import ops, quant
+    c = quant.constants(bits)
+    s, z = (c.w_s, c.w_z) if signed else (c.f_s, c.f_z)
+    x = _points(s, 50_000, bits * 2 + signed)
+    want = (QO.quantization_fbits if signed else QO.quantization_ufbits)(x.clone(), s, z, bits)
+    got = ops.fake_quantize(x.to(dev), signed, bits, s, z)
+    assert torch.equal(got.cpu(), want)
+    assert got.unique().numel() <= (2 ** bits if not signed else max(2, 2 ** bits - 1))
+
+
+@pytest.mark.parametrize("iq,scale_fea", [(16, 4), (8, 3), (4, 3), (4, 2), (16, 0)])
+def test_requantize_bit_exact(iq, scale_fea):
+    from sgracex1_amd import ops
+    g = torch.Generator().manual_seed(iq + scale_fea)
+    H = (torch.rand((3001, 37), generator=g) * 2 - 1) * 2 ** scale_fea * 1.2
+    H[0, :8] = torch.tensor([0.0, -0.0, 1e-9, 0.5, -0.5, 2.0 ** scale_fea, -2.0 ** scale_fea, 0.0625])
+    want = H / (2 ** scale_fea)
+    want = torch.clip(want, min=-(2 ** iq - 1) / (2 ** iq), max=(2 ** iq - 1) / (2 ** iq))
+    want = torch.round(want, decimals=iq - 1)
+    buf = torch.zeros((3001, 40), device=dev)                       # padded leading dimension, pad must stay 0
+    buf[:, :37] = H.to(dev)
+    ops.requantize_(buf[:, :37], scale_fea, iq)
+    assert torch.equal(buf[:, :37].cpu(), want)
+    assert (buf[:, 37:] == 0).all()
+
+
+def _graph_case(n, m, p, seed, density=0.02):
+    g = torch.Generator().manual_seed(seed)
+    adj = (torch.rand((n, n), generator=g) < density).float()
+    adj = ((adj + adj.t() + torch.eye(n)) > 0).float()
+    deg = adj.sum(1)
+    adj = adj / torch.sqrt(deg[:, None] * deg[None, :])
+    x = torch.rand((n, m), generator=g) * (torch.rand((n, m), generator=g) < 0.3)
+    w = (torch.rand((m, p), generator=g) * 2 - 1) * 0.7
+    att = (torch.rand((2 * p, 1), generator=g) * 2 - 1) * 0.7
+    return adj, x, w, att
+
+
+@pytest.mark.parametrize("bits", [8, 4, 2, 1])
+@pytest.mark.parametrize("gat", [0, 1])
+@pytest.mark.parametrize("sparse_x", [0, 1])
+def test_quantised_layer_matches_restatement(bits, gat, sparse_x):
+    from sgracex1_amd import ops, quant
+    n, m, p = 700, 150, 24
+    adj, x, w, att = _graph_case(n, m, p, 31 + bits + gat)
+    c = quant.constants(bits)
+    want, e_d, p_d, _wh = QO.layer(adj, x, w, att, c, relu=1, compute_attention=gat)
+    A = ops.Csr.from_dense(adj.to(dev), torch.float32)
+    X = ops.Csr.from_dense(x.to(dev), torch.float32) if sparse_x else x.to(dev)
+    Wt = w.t().contiguous().to(dev)
+    res = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att.reshape(-1).to(dev) if gat else None, quant=c,
+                            want_edge_outputs=bool(gat))
+    got = (res[0] if gat else res).cpu()
+    tol = dict(rtol=2e-5, atol=2e-6 * c.deq_o)
+    assert torch.allclose(got, want, **tol), float((got - want).abs().max())
+    assert want.abs().max() > 0
+    if gat:
+        idx = adj.nonzero().t()
+        kept = p_d[idx[0], idx[1]]                                  # softmax of the restatement on the stored edges
+        live = QO.quantization_ufbits(adj[idx[0], idx[1]].clone(), c.a_s, c.a_z, bits) > 0
+        S = res[2].cpu()
+        # edges the quantiser zeroed are masked (SG.py:640): 0, or 1/N in rows left without any live edge
+        assert torch.allclose(S, kept, rtol=1e-4, atol=1e-6)
+        assert bool(live.all()) or (S[~live] <= 1.0 / n + 1e-9).all()
+    # the adjacency quantised once by the host and flagged as such gives the same bits
+    Aq = ops.Csr(A.rowptr, A.col, ops.fake_quantize(A.val, 0, bits, c.a_s, c.a_z), A.n_cols)
+    res2 = ops.layer_forward(Aq, X, Wt, relu=True, gat_attention=att.reshape(-1).to(dev) if gat else None, quant=c,
+                             adj_quantized=True)
+    assert torch.equal(res2.cpu(), got)
+    if not gat:                                                     # ... and so does quantising it inside the call
+        res3 = ops.layer_forward(A, X, Wt, relu=True, quant=c, cache_quantized_adj=False)
+        assert torch.equal(res3.cpu(), got)
+
+
+def test_quantised_layer_rejects_half_tensors():
+    from sgracex1_amd import ops, quant
+    adj, x, w, _ = _graph_case(50, 10, 8, 3)
+    A = ops.Csr.from_dense(adj.to(dev), torch.float16)
+    with pytest.raises(TypeError):
+        ops.layer_forward(A, x.to(dev).half(), w.t().contiguous().to(dev).half(), quant=quant.constants(8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_gat_row_without_live_edge_follows_the_dense_emulation(dtype):
+    """SG.py:638-641: a row whose every entry is masked is constant before the softmax, so the
+    softmax is uniform over all N nodes and the row receives the mean of all rows of Wh."""
+    from sgracex1_amd import ops
+    n, p = 300, 24
+    adj, _x, _w, att = _graph_case(n, 10, p, 13, density=0.03)
+    adj[7, :] = 0                                   # no entry at all
+    adj[19, :] = -adj[19, :]                        # entries, none positive
+    g = torch.Generator().manual_seed(2)
+    Wh = (torch.rand((n, p), generator=g) - 0.3).to(dtype).float()
+    e = torch.nn.functional.leaky_relu(Wh @ att[:p] + (Wh @ att[p:]).T, 0.2)
+    attn = torch.softmax(torch.where(adj > 0, e, -9e15 * torch.ones_like(e)), dim=1)
+    want = attn @ Wh
+    A = ops.Csr.from_dense(adj.to(dev), dtype)
+    assert A.has_dead_rows
+    got, E, S = ops.gat_aggregate(A, Wh.to(dev).to(dtype), att.reshape(-1).to(dev).to(dtype), want_edge_outputs=True)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-3)
+    assert torch.allclose(got.float().cpu(), want, **tol)
+    assert torch.allclose(got[7].float().cpu(), Wh.mean(0), **tol) and torch.allclose(got[19].float().cpu(), Wh.mean(0), **tol)
+    rp = A.rowptr.cpu()
+    assert torch.allclose(S[rp[19]:rp[20]].cpu(), torch.full((int(rp[20] - rp[19]),), 1.0 / n))
+    # the layer entry point sets the same flag from the adjacency it is given
+    adj2 = adj.clone()
+    adj2[19, :] = 0
+    A2 = ops.Csr.from_dense(adj2.to(dev), dtype)
+    X = torch.eye(n, dtype=dtype, device=dev)
+    out = ops.layer_forward(A2, X, Wh.t().contiguous().to(dev).to(dtype), gat_attention=att.reshape(-1).to(dev).to(dtype))
+    assert torch.allclose(out.float().cpu(), want, **tol)
+
+
+@pytest.mark.parametrize("bits,gat", [(8, 0), (8, 1), (4, 0), (1, 1)])
+def test_sgrace_layers_quantised_on_the_gpu_match_the_dense_twin(bits, gat):
+    """GATConv_SGRACE with config.acc = 1 (kernels) against config.acc = 0 (dense emulation), two
+    stacked layers so that the hardware path's alternating constant sets are exercised."""
+    from sgracex1_amd import config, sgrace
+    adj, x, w1, att1 = _graph_case(300, 60, 16, 77 + bits)
+    _, _, w2, att2 = _graph_case(300, 16, 16, 78 + bits)
+    idx = adj.nonzero().t()
+    norm = adj[idx[0], idx[1]]
+    old = (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type, config.device)
+    outs = {}
+    try:
+        for acc in (0, 1):
+            config.acc, config.fake_quantization, config.w_qbits, config.compute_attention = acc, 1, bits, gat
+            config.float_type = np.float32
+            sgrace.init_SGRACE()
+            d = dev if acc else torch.device("cpu")
+            l1, l2 = sgrace.GATConv_SGRACE(60, 16).to(d), sgrace.GATConv_SGRACE(16, 16).to(d)
+            with torch.no_grad():
+                l1.weight.copy_(w1), l1.attention.copy_(att1), l2.weight.copy_(w2[:16]), l2.attention.copy_(att2)
+            h = l1(gat, 1, 1, x.to(d), idx.to(d), norm.to(d), adj.to_sparse().to(d) if not acc else adj.to(d).to_sparse())
+            # keep the second layer's input inside the feature range [0, 1] of the tables
+            h = torch.clamp(h, 0, 1)
+            out = l2(gat, 1, 0, h, idx.to(d), norm.to(d), adj.to_sparse().to(d) if not acc else adj.to(d).to_sparse())
+            out.sum().backward()
+            outs[acc] = (out.detach().cpu(), l1.weight.grad.detach().cpu())
+        # a 1-ulp difference in layer 1 can move a layer-2 input across a rounding boundary of the quantiser
+        close = torch.isclose(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-5)
+        assert close.float().mean() > 0.99, float((outs[1][0] - outs[0][0]).abs().max())
+        assert bits == 1 or outs[0][0].abs().max() > 0     # one bit: layer-2 inputs below 0.5 quantise to 0
+    finally:
+        (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type,
+         config.device) = old
+        sgrace.init_SGRACE()
+
+
+def test_register_path_carries_the_quantiser_registers():
+    """The notebook flow: host buffers, registers programmed as SG.py:334-365 / :476, AP_START."""
+    from sgracex1_amd import pynq_shim, quant
+    from sgracex1_amd.sgrace import _program_quant_registers
+    n, m, p = 200, 40, 8
+    adj, x, w, att = _graph_case(n, m, p, 91, density=0.05)
+    c = quant.constants(8)
+    want, _e, _p, _wh = QO.layer(adj, x, w, att, c, relu=1, compute_attention=0)
+    ol = pynq_shim.Overlay("gat_all_unsigned.bit")
+    ip = ol.mmult_top_0
+    rm = ip.register_map
+    idx = adj.nonzero().t().numpy()
+    nnz = idx.shape[1]
+    bufs = {name: pynq_shim.allocate(shape, dt) for name, shape, dt in [
+        ("row", nnz, np.int32), ("col", nnz, np.int32), ("val", nnz, np.float32), ("B", p * m, np.float32),
+        ("X", n * m, np.float32), ("D", n * p, np.float32)]}
+    bufs["row"][:], bufs["col"][:] = idx[0], idx[1]
+    bufs["val"][:] = adj.numpy()[idx[0], idx[1]]
+    bufs["B"][:] = w.t().contiguous().numpy().reshape(-1)
+    bufs["X"][:] = x.numpy().reshape(-1)
+    rm.gemm_mode, rm.relu, rm.gat_mode = 1, 1, 0
+    rm.N_adj, rm.M_adj, rm.M_fea, rm.P_w, rm.nnz_adj1 = n, n, m, p, nnz
+    rm.rowPtr_adj1_offset_1, rm.columnIndex_adj1_offset_1 = bufs["row"].physical_address, bufs["col"].physical_address
+    rm.values_adj1_offset_1, rm.B_offset_1 = bufs["val"].physical_address, bufs["B"].physical_address
+    rm.values_fea1_offset_1, rm.D1_offset_1 = bufs["X"].physical_address, bufs["D"].physical_address
+    rm.beta_qu, rm.f_align = 255, 0
+    _program_quant_registers(rm, c)
+    qc = ip.quant_from_registers()
+    assert qc.w_qbits == 8 and qc.scale_fea == 4 and qc.internal_quantization == 16
+    assert np.float32(1 / qc.f_s) == np.float32(1 / c.f_s) and np.float32(qc.deq_o) == np.float32(c.deq_o)
+    rm.CTRL.AP_START = 1
+    assert rm.CTRL.AP_DONE == 1
+    got = torch.from_numpy(np.asarray(bufs["D"]).reshape(n, p).copy())
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-6 * c.deq_o)
