@@ -227,10 +227,13 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
 /* GAT aggregation on an already computed Wh (SG.py:309-314, :634-661), single head:
  *   e_ij = LeakyReLU_alpha(Wh_i.a1 + Wh_j.a2) for stored edges with values[e] > 0,
  *   alpha_ij = softmax_j(e_ij),  D_i = act(sum_j alpha_ij Wh_j).
+ * Wh has n_cols rows; row r of the adjacency is node r of Wh (n_rows <= n_cols: the reference's
+ * square case is n_rows == n_cols, a rank of the partitioned graph passes its own rows first and
+ * the halo rows behind them).
  * fill_dead_rows: see sgx_layer_desc.gat_fill_dead_rows.  s_scratch: sgx_gat_scratch_bytes() bytes
  * (the per-node scores Wh.a1, Wh.a2 and the column-mean partials).  E/S optional [nnz] fp32. */
-size_t sgx_gat_scratch_bytes(int n_rows, int n_feat, int fill_dead_rows);
-int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_feat, float alpha,
+size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int fill_dead_rows);
+int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, float alpha,
                       const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                       const void *Wh, int64_t ldh, const void *attention,
                       void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream);

@@ -69,7 +69,7 @@ __device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, floa
 
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
-    int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    int n_rows, int n_cols, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
     T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     }
     const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
     const bool dead = live && !(l > 0.0f) && fill != nullptr;
-    const float uniform = 1.0f / (float)n_rows;
+    const float uniform = 1.0f / (float)n_cols;
 
     // pass 2: weighted gather of the neighbour rows
     for (int c0 = 0; c0 < n_feat; c0 += TILE) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void col_mean_finish_kernel(int n_rows, int
 }
 
 struct GatArgs {
-    int relu, n_rows, n_feat;
+    int relu, n_rows, n_cols, n_feat;
     float alpha;
     const int32_t *rowptr, *col;
     const void *val, *Wh, *att;
@@ -208,11 +208,12 @@ int gat_launch_one(const GatArgs &a)
 {
     const int rows_per_block = (64 / LPR) * (kBlock / 64);
     const unsigned grid = (unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block);
-    float *s1 = a.s, *s2 = a.s + a.n_rows;
-    hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_feat,
+    const unsigned grid_s = (unsigned)((a.n_cols + rows_per_block - 1) / rows_per_block);
+    float *s1 = a.s, *s2 = a.s + a.n_cols;                    // scores of every row of the table
+    hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid_s), dim3(kBlock), 0, a.stream, a.n_cols, a.n_feat,
                        (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2, a.vec_ok);
     SGX_LAUNCH_CHECK();
-    hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_feat,
+    hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_cols, a.n_feat,
                        a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
                        (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill);
     SGX_LAUNCH_CHECK();
@@ -235,43 +236,43 @@ int gat_launch_lpr(const GatArgs &a, int lpr)
 
 }  // namespace
 
-extern "C" size_t sgx_gat_scratch_bytes(int n_rows, int n_feat, int fill_dead_rows)
+extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int fill_dead_rows)
 {
-    if (n_rows < 0 || n_feat < 1) return 0;
-    size_t floats = (size_t)2 * n_rows;
+    if (n_cols < 0 || n_feat < 1) return 0;
+    size_t floats = (size_t)2 * n_cols;
     if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
     return sgx_align_up(floats * sizeof(float), 256);
 }
 
-extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_feat, float alpha,
+extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, float alpha,
                                  const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                                  const void *Wh, int64_t ldh, const void *attention,
                                  void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream)
 {
-    if (n_rows < 0 || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
+    if (n_rows < 0 || n_cols < n_rows || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
     if (!rowPtr || !columnIndex || !values || !Wh || !attention || !D) return SGX_ERR_NULL;
     if (!s_scratch) return SGX_ERR_WORKSPACE;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
     const size_t es = sgx_elem_size(dtype);
-    const unsigned long long table_bytes = (unsigned long long)n_rows * (unsigned long long)ldh * es;
+    const unsigned long long table_bytes = (unsigned long long)n_cols * (unsigned long long)ldh * es;
     if (table_bytes >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
     GatArgs a;
-    a.relu = relu; a.n_rows = n_rows; a.n_feat = n_feat; a.alpha = alpha;
+    a.relu = relu; a.n_rows = n_rows; a.n_cols = n_cols; a.n_feat = n_feat; a.alpha = alpha;
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
     a.fill = nullptr;
     if (fill_dead_rows) {
-        float *partial = s_scratch + (size_t)2 * n_rows, *mean = partial + (size_t)kMeanSlabs * n_feat;
+        float *partial = s_scratch + (size_t)2 * n_cols, *mean = partial + (size_t)kMeanSlabs * n_feat;
         if (dtype == SGX_F16)
-            hipLaunchKernelGGL(col_sum_slab_kernel<f16>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_rows, n_feat,
+            hipLaunchKernelGGL(col_sum_slab_kernel<f16>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_cols, n_feat,
                                (const f16 *)Wh, ldh, partial);
         else
-            hipLaunchKernelGGL(col_sum_slab_kernel<float>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_rows, n_feat,
+            hipLaunchKernelGGL(col_sum_slab_kernel<float>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_cols, n_feat,
                                (const float *)Wh, ldh, partial);
         SGX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(col_mean_finish_kernel, dim3((n_feat + kBlock - 1) / kBlock), dim3(kBlock), 0, a.stream, n_rows,
+        hipLaunchKernelGGL(col_mean_finish_kernel, dim3((n_feat + kBlock - 1) / kBlock), dim3(kBlock), 0, a.stream, n_cols,
                            n_feat, partial, mean);
         SGX_LAUNCH_CHECK();
         a.fill = mean;

@@ -64,7 +64,8 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                     const void *H, int64_t ldh, void *D, int64_t ldd,
                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
-                    const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0);
+                    const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0,
+                    bool fea_stage = false);
 
 // D *= factor, fp32 (the deq_o step of the quantised layer, quant.hip)
 int sgx_scale_f32(int64_t n, float *D, float factor, hipStream_t s);

@@ -129,6 +129,7 @@ class Backend:
     spmm: Callable
     spmm_partial: Optional[Callable] = None
     spmm_finish: Optional[Callable] = None
+    gat: Optional[Callable] = None      # gat(adj_compact, table, attention, alpha, relu) -> D_local (edge softmax)
 
 
 def hip_backend():
@@ -142,7 +143,9 @@ def hip_backend():
 
     return Backend(xw=xw, spmm=lambda adj, table, relu: ops.spmm(adj, table, relu=relu),
                    spmm_partial=lambda adj, table: ops.spmm_acc(adj, table, partial_out=True),
-                   spmm_finish=lambda adj, table, partial, relu: ops.spmm_acc(adj, table, relu=relu, acc_in=partial))
+                   spmm_finish=lambda adj, table, partial, relu: ops.spmm_acc(adj, table, relu=relu, acc_in=partial),
+                   gat=lambda adj, table, att, alpha, relu: ops.gat_aggregate(adj, table, att, alpha=alpha, relu=relu,
+                                                                              fill_dead_rows=False))
 
 
 def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None):
@@ -167,8 +170,13 @@ def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, gr
     return backend.spmm(adj_local, h_global, relu)
 
 
-def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPlan, group=None, table=None):
-    """adj_compact: rows of this rank with column indices already remapped by build_halo_plan."""
+def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPlan, group=None, table=None,
+               attention=None, alpha=0.2):
+    """adj_compact: rows of this rank with column indices already remapped by build_halo_plan.
+    attention: the GAT vector a [2P] -> the edge-softmax aggregate instead of A.H.  The softmax is
+    row-local, so the same halo rows serve it: the scores Wh.a2 of the halo rows are recomputed from
+    the received rows, own row r is row r of the compact table.  (Rows left without a live edge give
+    0 here: the dense emulation's mean over ALL nodes would need one more reduction across ranks.)"""
     h_local = backend.xw(fea_local, Wt)
     P = h_local.shape[1]
     if table is None:
@@ -176,6 +184,8 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     table[:plan.n_own] = h_local
     packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
     all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
+    if attention is not None:
+        return backend.gat(adj_compact, table, attention, alpha, relu)
     return backend.spmm(adj_compact, table, relu)
 
 

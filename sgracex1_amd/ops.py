@@ -345,19 +345,25 @@ def requantize_(H, scale_fea, internal_bits):
     return H
 
 
-def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False):
+def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False, fill_dead_rows=None, out=None):
+    """Edge-softmax aggregate over an already computed Wh [adj.n_cols, F]; row r of adj is node r of Wh.
+    fill_dead_rows: None = decide from the adjacency (rows without a positive entry get the mean of
+    all rows of Wh, as in the reference's dense emulation), False = such rows give 0."""
     _dev2d(Wh, "Wh")
     code = dtype_code(Wh.dtype)
     N, F = Wh.shape
+    if N != adj.n_cols or adj.n_rows > N:
+        raise ValueError(f"Wh must have adj.n_cols = {adj.n_cols} rows (got {N}) and adj.n_rows <= adj.n_cols")
     att = _dev(attention, "attention").reshape(-1)
-    out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
+    if out is None:
+        out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
     E = S = None
     if want_edge_outputs:
         E = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
         S = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
-    fill = int(adj.has_dead_rows)
-    s = torch.empty(lib.sgx_gat_scratch_bytes(adj.n_rows, F, fill) // 4, dtype=torch.float32, device=Wh.device)
-    check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
+    fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
+    s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, fill) // 4, dtype=torch.float32, device=Wh.device)
+    check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
                                 _ptr(E), _ptr(S), _ptr(s), _stream()), "sgx_gat_aggregate")
     return (out, E, S) if want_edge_outputs else out

@@ -62,7 +62,20 @@ def _worker(rank, world, port, tmp, balance_nnz):
             out = partial + spmm(adj, table, False)
             return torch.clamp(out, min=0) if relu else out
 
-        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish)
+        def gat(adj, table, att, alpha, relu):                  # SG.py:634-661 on the rank's rows, dense
+            n_loc, n_tab = adj.rowptr.numel() - 1, table.shape[0]
+            deg = (adj.rowptr[1:] - adj.rowptr[:-1]).long()
+            rows = torch.repeat_interleave(torch.arange(n_loc), deg)
+            mask = torch.zeros((n_loc, n_tab))
+            mask[rows, adj.col.long()] = (adj.val > 0).float()
+            Pn = table.shape[1]
+            e = torch.nn.functional.leaky_relu((table[:n_loc] @ att[:Pn])[:, None] + (table @ att[Pn:])[None, :], alpha)
+            a = torch.softmax(torch.where(mask > 0, e, torch.full_like(e, -9e15)), dim=1)
+            a = torch.where(mask.sum(1, keepdim=True) > 0, a, torch.zeros_like(a))
+            out = a @ table
+            return torch.clamp(out, min=0) if relu else out
+
+        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish, gat=gat)
         trp, tci, tva = torch.as_tensor(rp), torch.as_tensor(ci), torch.as_tensor(va)
         bounds = D.row_partition(n, world, trp if balance_nnz else None)
         assert bounds[0] == 0 and bounds[-1] == n and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
@@ -102,6 +115,18 @@ def _worker(rank, world, port, tmp, balance_nnz):
         d3 = D.layer_halo_overlap(backend, LocalCsr(*own, plan.n_own), LocalCsr(*halo, sum(plan.recv_counts)), Xl, Wt,
                                   True, plan)
         np.testing.assert_allclose(d3.numpy(), want[lo:hi], rtol=1e-5, atol=1e-5)
+        # GAT over the same halo rows against the single-process dense formula
+        att = torch.as_tensor(rng.standard_normal(2 * p).astype(np.float32)) * 0.3
+        H_all = H_full
+        pos = torch.zeros((n, n))
+        deg_all = np.diff(rp)
+        pos[np.repeat(np.arange(n), deg_all), ci.astype(np.int64)] = torch.as_tensor((va > 0).astype(np.float32))
+        e_all = torch.nn.functional.leaky_relu((H_all @ att[:p])[:, None] + (H_all @ att[p:])[None, :], 0.2)
+        a_all = torch.softmax(torch.where(pos > 0, e_all, torch.full_like(e_all, -9e15)), dim=1)
+        a_all = torch.where(pos.sum(1, keepdim=True) > 0, a_all, torch.zeros_like(a_all))
+        want_gat = torch.clamp(a_all @ H_all, min=0)
+        d4 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan, attention=att)
+        np.testing.assert_allclose(d4.numpy(), want_gat[lo:hi].numpy(), rtol=1e-4, atol=1e-5)
         # bytes moved: the halo exchange never receives more rows than the all-gather would
         assert sum(plan.recv_counts) <= n - (hi - lo)
         sent = torch.tensor([sum(plan.send_counts)], dtype=torch.int64)

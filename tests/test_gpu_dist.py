@@ -47,6 +47,12 @@ def _worker(rank, world, port, tmp):
         # two passes sum the same terms in another order: equal to fp32 rounding, not bitwise
         assert torch.allclose(d3.float(), want[lo:hi].float(), rtol=2e-3, atol=2e-3)
         assert (d3 == want[lo:hi]).float().mean() > 0.98
+        # GAT shards the same way (row-local softmax): own row r is row r of the compact table
+        att = ((torch.rand(2 * p, generator=g, device=dev) - 0.5) / 2).half()
+        want_gat = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att)
+        d4 = D.layer_halo(backend, ops.Csr(rp, plan.col_compact, va, plan.n_table), X[lo:hi].contiguous(), Wt, True, plan,
+                          attention=att)
+        assert torch.equal(d4, want_gat[lo:hi])
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
