@@ -156,6 +156,12 @@ typedef struct sgx_layer_desc {
     void          *E;                 /* optional out [nnz_adj] fp32: LeakyReLU(e_ij)        */
     void          *S;                 /* optional out [nnz_adj] fp32: softmax alpha_ij       */
     float          alpha;             /* LeakyReLU slope (SG.py:1172, default 0.2)           */
+    /* FEA_THREADS / ADJ_THREADS of the reference (MM.h:166-167; 1, 2 or 4 there): each stage's rows
+     * are cut into that many contiguous blocks -- rows/threads each, the remainder to the last
+     * (K.cpp:3159-3164, :3517-3523) -- and the SPMM_BLOCK grouping restarts at every block.  Like
+     * spmm_block only observable in SGX_ACC_REF_HALF; 0 means 1. */
+    int32_t        fea_threads;
+    int32_t        adj_threads;
     int32_t        reserved1;
 
     /* scratch in HBM for H = X.W (the reference's on-chip C tile, K.cpp:27) and split-row

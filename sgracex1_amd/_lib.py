@@ -65,7 +65,8 @@ class LayerDesc(ctypes.Structure):
         ("rowPtr_fea", ctypes.c_void_p), ("columnIndex_fea", ctypes.c_void_p), ("values_fea", ctypes.c_void_p),
         ("rowPtr_adj", ctypes.c_void_p), ("columnIndex_adj", ctypes.c_void_p), ("values_adj", ctypes.c_void_p),
         ("attention", ctypes.c_void_p), ("E", ctypes.c_void_p), ("S", ctypes.c_void_p),
-        ("alpha", ctypes.c_float), ("reserved1", ctypes.c_int32),
+        ("alpha", ctypes.c_float), ("fea_threads", ctypes.c_int32), ("adj_threads", ctypes.c_int32),
+        ("reserved1", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("plan_adj", ctypes.c_void_p), ("plan_fea", ctypes.c_void_p),
         ("ev_agg_begin", ctypes.c_void_p), ("ev_agg_end", ctypes.c_void_p),

@@ -86,6 +86,10 @@ extern "C" int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows
                            /*fea_stage*/true);
 }
 
+namespace {
+int thread_count(int32_t t) { return t < 1 ? 1 : t; }
+}
+
 extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
 {
     int rc = check_desc(d);
@@ -138,8 +142,14 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     if (d->gemm_mode == 0) {
         rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, B, d->M_fea, W, ldh, s);         // B [P][M] -> W [M][ldh]
         if (rc != SGX_OK) return rc;
-        rc = sgx_xw_sparse(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
-                           d->columnIndex_fea, values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s);
+        rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, /*relu*/0, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
+                             d->columnIndex_fea, values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s, nullptr,
+                             nullptr, 0, /*fea_stage*/true, thread_count(d->fea_threads));
+    } else if (d->acc_mode == SGX_ACC_REF_HALF && thread_count(d->fea_threads) > 1) {
+        if (d->dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
+        if (ldh > d->P_w) SGX_HIP_CHECK(hipMemsetAsync(H, 0, (size_t)d->M_adj * ldh * sizeof(f16), s));
+        rc = sgx_refhalf_dense(d->spmm_block, d->fea_threads, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
+                               H, ldh, s);
     } else {
         rc = sgx_xw_dense(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
                           H, ldh, s);
@@ -160,7 +170,7 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     } else {
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,
                              d->rowPtr_adj, d->columnIndex_adj, values_adj, H, ldh, d->D, d->P_w, d->plan_adj,
-                             scratch, c.s_bytes, s);
+                             scratch, c.s_bytes, s, nullptr, nullptr, 0, /*fea_stage*/false, thread_count(d->adj_threads));
     }
     if (rc != SGX_OK) return rc;
     if (q) {                                                                            // SG.py:666-667

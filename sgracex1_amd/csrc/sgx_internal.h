@@ -55,9 +55,9 @@ static inline int64_t sgx_ldh(int dtype, int P) {
 }
 
 // SGX_ACC_REF_HALF stages (refhalf.hip), fp16 only
-int sgx_refhalf_csr(int spmm_block, int relu, int n_rows, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
+int sgx_refhalf_csr(int spmm_block, int threads, int relu, int n_rows, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
                     const void *values, const void *table, int64_t ldt, void *out, int64_t ldo, hipStream_t s);
-int sgx_refhalf_dense(int spmm_block, int n_rows, int M, int n_feat, const void *X, int64_t ldx, const void *Wt,
+int sgx_refhalf_dense(int spmm_block, int threads, int n_rows, int M, int n_feat, const void *X, int64_t ldx, const void *Wt,
                       int64_t ldw, void *out, int64_t ldo, hipStream_t s);
 
 int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_rows, int n_cols, int n_feat,
@@ -65,7 +65,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const void *H, int64_t ldh, void *D, int64_t ldd,
                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
                     const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0,
-                    bool fea_stage = false);
+                    bool fea_stage = false, int ref_threads = 1);
 
 // D *= factor, fp32 (the deq_o step of the quantised layer, quant.hip)
 int sgx_scale_f32(int64_t n, float *D, float factor, hipStream_t s);

@@ -404,7 +404,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                     const void *H, int64_t ldh, void *D, int64_t ldd,
                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
-                    const float *acc_in, float *acc_out, int64_t ld_acc, bool fea_stage)
+                    const float *acc_in, float *acc_out, int64_t ld_acc, bool fea_stage, int ref_threads)
 {
     (void)spmm_block;
     if (n_rows < 0 || n_cols < 0 || n_feat < 1 || ldh < n_feat) return SGX_ERR_SHAPE;
@@ -416,7 +416,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     if (acc_mode == SGX_ACC_REF_HALF) {
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
         if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
-        return sgx_refhalf_csr(spmm_block, relu, n_rows, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, stream);
+        return sgx_refhalf_csr(spmm_block, ref_threads, relu, n_rows, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, stream);
     }
     if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;

@@ -333,7 +333,7 @@ extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows,
         // the reference's sequential half arithmetic (refhalf.hip)
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
         if (ldh > P) SGX_HIP_CHECK(hipMemsetAsync(H, 0, (size_t)n_rows * ldh * sizeof(f16), s));
-        return sgx_refhalf_dense(spmm_block, n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, s);
+        return sgx_refhalf_dense(spmm_block, 1, n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, s);
     }
     if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     const size_t es = sgx_elem_size(dtype);

@@ -255,7 +255,7 @@ def transpose(x, ldo=None):
 
 def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
                   acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None,
-                  quant=None, adj_quantized=False, cache_quantized_adj=True):
+                  quant=None, adj_quantized=False, cache_quantized_adj=True, fea_threads=1, adj_threads=1):
     """One fused layer  D = act(A . (X . W))  through sgx_layer_forward.
 
     adj : Csr [N, M_adj];  fea : Csr [M_adj, M_fea] (gemm_mode 0) or dense tensor (gemm_mode 1);
@@ -274,6 +274,7 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     d.gemm_mode, d.relu, d.gat_mode = gemm_mode, int(bool(relu)), int(gat_attention is not None)
     d.N_adj, d.M_adj, d.M_fea, d.P_w = adj.n_rows, adj.n_cols, M_fea, P
     d.bias_count, d.dtype, d.acc_mode, d.spmm_block = bias_count, code, acc_mode, spmm_block
+    d.fea_threads, d.adj_threads = int(fea_threads), int(adj_threads)      # observable in SGX_ACC_REF_HALF only
     if adj.val.dtype != Wt.dtype:
         raise TypeError("adjacency, features and weights must share one element type (MM.h:129-139)")
     if quant is not None and Wt.dtype != torch.float32:

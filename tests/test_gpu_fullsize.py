@@ -1,0 +1,137 @@
+"""The bench workload at its full size (S-100M: 4.2 M nodes, ~104 M edges, hidden 64, sparse
+first layer) checked through properties that do not need a CPU pass over the whole graph:
+
+  * sampled rows against the oracle (the rows' edges and the table rows they touch are copied out);
+  * a checksum of checksums: column sums of D against sums formed edge by edge with torch ops;
+  * constant table -> row sums of A;  linearity in the table;  ReLU = clamp of the linear result;
+  * the same bits on a second run, with and without the row schedule;
+  * both layers of the forward pass end to end on sampled rows.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+dev = torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def workload():
+    import bench
+    from sgracex1_amd import graphs, ops
+    wl = bench.WORKLOADS["s100m"]
+    A, X, W1t, W2t = bench.make_inputs(torch, graphs, ops, wl, 0, 1, dev)
+    A.plan
+    X.plan
+    yield A, X, W1t, W2t
+    del A, X
+    torch.cuda.empty_cache()
+
+
+def _sample_rows(A, rows):
+    """(rowptr, compact col, val, unique table rows) of the given rows of A, on the host."""
+    rp = A.rowptr
+    starts, ends = rp[rows].long(), rp[rows + 1].long()
+    deg = ends - starts
+    off = torch.repeat_interleave(starts - torch.cumsum(deg, 0) + deg, deg)
+    idx = off + torch.arange(int(deg.sum()), device=rp.device)
+    col, val = A.col[idx].long(), A.val[idx]
+    uniq, inv = torch.unique(col, return_inverse=True)
+    srp = torch.zeros(rows.numel() + 1, dtype=torch.int32)
+    srp[1:] = torch.cumsum(deg, 0).cpu().to(torch.int32)
+    return srp.numpy(), inv.cpu().numpy().astype(np.int32), val.float().cpu().numpy(), uniq
+
+
+def test_full_size_aggregation_properties(workload, oracle):
+    from sgracex1_amd import ops
+    A, _X, _W1t, _W2t = workload
+    n, P = A.n_rows, 64
+    assert n == 1 << 22 and A.nnz > 100_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    H = (torch.rand((n, P), generator=g, device=dev) - 0.25).half()
+    D = ops.spmm(A, H, relu=False)
+    # same bits on a second run and without the row schedule
+    assert torch.equal(ops.spmm(A, H, relu=False), D)
+    assert torch.equal(ops.spmm(A, H, relu=False, use_plan=False), D)
+    # ReLU is the clamp of the linear result (K.cpp:2586-2590)
+    Dr = ops.spmm(A, H, relu=True)
+    assert torch.equal(Dr, torch.where(D > 0, D, torch.zeros_like(D)))
+
+    # sampled rows against the oracle
+    gr = torch.Generator(device=dev)
+    gr.manual_seed(6)
+    rows = torch.randint(0, n, (4096,), generator=gr, device=dev).sort().values
+    srp, scol, sval, uniq = _sample_rows(A, rows)
+    table = H[uniq].float().cpu().numpy()
+    want = oracle.spmm_f32(0, (srp, scol, sval), table)
+    got = D[rows].float().cpu().numpy()
+    # fp32 sums of <= a few dozen terms, one rounding to fp16: within one half-ulp step of the oracle's fp32 result
+    want16 = want.astype(np.float16).astype(np.float32)
+    assert np.mean(got == want16) > 0.999
+    np.testing.assert_allclose(got, want, rtol=1.5e-3, atol=1e-4)
+
+    # checksum of checksums: column sums of D against edge-by-edge sums formed by torch
+    col_sum = torch.zeros(P, dtype=torch.float64, device=dev)
+    step = 8_000_000
+    for e0 in range(0, A.nnz, step):
+        e1 = min(A.nnz, e0 + step)
+        col_sum += (A.val[e0:e1].double()[:, None] * H[A.col[e0:e1].long()].double()).sum(0)
+    got_sum = D.double().sum(0)
+    # each D element carries one fp16 rounding (rel 2^-11, zero mean); the sum of 4.2 M of them
+    scale = D.double().abs().sum(0)
+    assert ((got_sum - col_sum).abs() <= scale * 2.0 ** -11 * 0.02 + 1e-6).all(), (got_sum - col_sum, scale)
+
+    # constant table -> row sums of A
+    ones = torch.ones((n, 8), dtype=torch.float16, device=dev)
+    rs = ops.spmm(A, ones, relu=False)
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    want_rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, A.val.double())
+    assert (rs.double() - want_rs[:, None]).abs().max() <= 2.0 ** -10 * float(want_rs.max())
+    assert torch.equal(rs[:, 0], rs[:, 7])
+
+    # linearity in the table (fp32 tensors: the only roundings left are those of the sums)
+    A32 = ops.Csr(A.rowptr, A.col, A.val.float(), A.n_cols, A._plan)
+    H1 = torch.rand((n, 16), generator=g, device=dev)
+    H2 = torch.rand((n, 16), generator=g, device=dev)
+    lhs = ops.spmm(A32, H1 + 2 * H2, relu=False)
+    rhs = ops.spmm(A32, H1, relu=False) + 2 * ops.spmm(A32, H2, relu=False)
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_two_layer_forward_on_sampled_rows(workload, oracle):
+    """Both layers of the bench step; the sampled output rows are recomputed by the oracle from the
+    GPU's own intermediate tables (H1 = X.W1, D1, H2 = D1.W2), each stage on its own."""
+    from sgracex1_amd import ops
+    A, X, W1t, W2t = workload
+    n = A.n_rows
+    D1 = ops.layer_forward(A, X, W1t, relu=True)
+    D2 = ops.layer_forward(A, D1, W2t, relu=False)
+    gr = torch.Generator(device=dev)
+    gr.manual_seed(9)
+    rows = torch.randint(0, n, (2048,), generator=gr, device=dev).sort().values
+
+    # stage 1 on the sampled rows: sparse X . W1
+    xrp, xcol, xval, xuniq = _sample_rows(X, rows)
+    W1 = ops.transpose(W1t)                                   # [F_in, hidden]
+    H1 = ops.spmm(X, W1, relu=False)
+    want_h1 = oracle.spmm_f32(0, (xrp, xcol, xval), W1[xuniq].float().cpu().numpy())
+    np.testing.assert_allclose(H1[rows].float().cpu().numpy(), want_h1, rtol=2e-3, atol=2e-4)
+    # stage 2: A . H1 with ReLU
+    arp, acol, aval, auniq = _sample_rows(A, rows)
+    want_d1 = oracle.spmm_f32(1, (arp, acol, aval), H1[auniq].float().cpu().numpy())
+    np.testing.assert_allclose(D1[rows].float().cpu().numpy(), want_d1, rtol=2e-3, atol=2e-4)
+    # stage 3: dense D1 . W2
+    H2 = ops.xw_dense(D1, W2t)
+    want_h2 = D1[rows].float().cpu().numpy() @ W2t.float().cpu().numpy().T
+    np.testing.assert_allclose(H2[rows].float().cpu().numpy(), want_h2, rtol=2e-3, atol=3e-4)
+    # stage 4: A . H2
+    want_d2 = oracle.spmm_f32(0, (arp, acol, aval), H2[auniq].float().cpu().numpy())
+    np.testing.assert_allclose(D2[rows].float().cpu().numpy(), want_d2, rtol=2e-3, atol=3e-4)
+    assert torch.isfinite(D2.float()).all() and float(D2.float().abs().max()) > 0

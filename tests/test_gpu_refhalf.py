@@ -79,3 +79,29 @@ def test_stage_entry_points_in_reference_arithmetic(oracle):
     assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
     with pytest.raises(RuntimeError):                                          # fp32 has no reference-half form
         ops.spmm(A.to(torch.float32), _dev(H).float(), acc_mode=ops.SGX_ACC_REF_HALF)
+
+
+@pytest.mark.parametrize("name", ["mol", "cora", "test"])
+@pytest.mark.parametrize("fea_threads,adj_threads,spmm_block", [(2, 2, 4), (4, 1, 4), (1, 4, 2), (4, 4, 1), (2, 4, 3)])
+def test_layer_bit_exact_with_thread_splits(oracle, name, fea_threads, adj_threads, spmm_block):
+    """FEA_THREADS / ADJ_THREADS of the reference (MM.h:166-167): contiguous row blocks, the sblock
+    grouping restarts at each block (K.cpp:3159-3164, :3517-3523) -- sparse and dense features."""
+    from sgracex1_amd import ops
+    d = load(name)
+    A, X = _csr(ops, d["adj"], d["N"]), _csr(ops, d["fea"], d["M_fea"])
+    Wt = _dev(d["Wt"], torch.float16)
+    kw = dict(spmm_block=spmm_block, fea_threads=fea_threads, adj_threads=adj_threads)
+    want = oracle.layer_refhalf(0, 1, d["adj"], d["fea"], d["Wt"], **kw)
+    got = ops.layer_forward(A, X, Wt, relu=1, acc_mode=ops.SGX_ACC_REF_HALF, **kw)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    if name == "cora" and spmm_block > 1:          # 2708 rows: every split above re-phases sblocks, tens of thousands of outputs move
+        one = oracle.layer_refhalf(0, 1, d["adj"], d["fea"], d["Wt"], spmm_block=spmm_block)
+        assert (one.view(np.uint16) != want.view(np.uint16)).sum() > 1000
+    # dense features: the layer's own output fed back through a square weight matrix
+    h = want.astype(np.float16)
+    P = h.shape[1]
+    rng = np.random.default_rng(3)
+    w2t = (rng.standard_normal((P, P)) * 0.3).astype(np.float16)
+    want2 = oracle.layer_refhalf(1, 0, d["adj"], h, w2t, **kw)
+    got2 = ops.layer_forward(A, _dev(h), _dev(w2t), relu=0, acc_mode=ops.SGX_ACC_REF_HALF, **kw)
+    assert np.array_equal(got2.cpu().numpy().view(np.uint16), want2.view(np.uint16))
