@@ -162,7 +162,8 @@ typedef struct sgx_layer_desc {
      * spmm_block only observable in SGX_ACC_REF_HALF; 0 means 1. */
     int32_t        fea_threads;
     int32_t        adj_threads;
-    int32_t        reserved1;
+    int32_t        gat_heads;         /* gat_mode: number of heads (see sgx_gat_aggregate); 0 means 1; the
+                                         attention buffer then holds gat_heads vectors of 2*P_w/gat_heads */
 
     /* scratch in HBM for H = X.W (the reference's on-chip C tile, K.cpp:27) and split-row
      * partial sums; at least sgx_layer_workspace_bytes(desc) bytes, 256-byte aligned */
@@ -237,9 +238,13 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
  * square case is n_rows == n_cols, a rank of the partitioned graph passes its own rows first and
  * the halo rows behind them).
  * fill_dead_rows: see sgx_layer_desc.gat_fill_dead_rows.  s_scratch: sgx_gat_scratch_bytes() bytes
- * (the per-node scores Wh.a1, Wh.a2 and the column-mean partials).  E/S optional [nnz] fp32. */
-size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int fill_dead_rows);
-int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, float alpha,
+ * (the per-node scores Wh.a1, Wh.a2 and the column-mean partials).  E/S optional [nnz] fp32.
+ * n_heads > 1 (BASELINE config 5; the reference itself has one head, SG.py:1176-1178): the formula
+ * above on each slice of n_feat / n_heads columns with its own vector attention[h][0 : 2*F_head],
+ * outputs concatenated -- what n_heads single-head calls on the slices give; E/S are [nnz][n_heads]. */
+size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows);
+int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads,
+                      float alpha,
                       const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                       const void *Wh, int64_t ldh, const void *attention,
                       void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream);

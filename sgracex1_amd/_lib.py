@@ -66,7 +66,7 @@ class LayerDesc(ctypes.Structure):
         ("rowPtr_adj", ctypes.c_void_p), ("columnIndex_adj", ctypes.c_void_p), ("values_adj", ctypes.c_void_p),
         ("attention", ctypes.c_void_p), ("E", ctypes.c_void_p), ("S", ctypes.c_void_p),
         ("alpha", ctypes.c_float), ("fea_threads", ctypes.c_int32), ("adj_threads", ctypes.c_int32),
-        ("reserved1", ctypes.c_int32),
+        ("gat_heads", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("plan_adj", ctypes.c_void_p), ("plan_fea", ctypes.c_void_p),
         ("ev_agg_begin", ctypes.c_void_p), ("ev_agg_end", ctypes.c_void_p),
@@ -114,9 +114,9 @@ def _load():
     lib.sgx_xw_sparse.restype = c_int
     lib.sgx_transpose.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp]
     lib.sgx_transpose.restype = c_int
-    lib.sgx_gat_scratch_bytes.argtypes = [c_int, c_int, c_int]
+    lib.sgx_gat_scratch_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.sgx_gat_scratch_bytes.restype = sz
-    lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
+    lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
                                       vp, c_i64, vp, vp, vp, vp]
     lib.sgx_gat_aggregate.restype = c_int
     lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]

@@ -162,6 +162,135 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Several heads (BASELINE config 5: 8 heads on ogbn-arxiv).  The reference has one head -- its
+// `nheads` only widens W (SG.py:1176-1178) -- so this is that single-head formula applied to each
+// slice of F_head = n_feat / n_heads columns with its own attention vector
+// a_h = attention[h][0 : 2*F_head], outputs concatenated: what n_heads single-head calls on the
+// column slices give, in one pass over the edges.  A lane owns VEC columns of one head; it walks
+// all edges of its row for that head (scores are 4-byte reads of the per-node, per-head table), so
+// no reduction across lanes is needed and each neighbour row is still gathered once.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_scores_heads_kernel(int n_cols, int n_heads, int f_head,
+                                                                 const T *__restrict__ Wh, int64_t ldh,
+                                                                 const T *__restrict__ att, float *__restrict__ s1,
+                                                                 float *__restrict__ s2)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)n_cols * n_heads) return;
+    const int64_t r = gid / n_heads;
+    const int h = (int)(gid - r * n_heads);
+    const T *w = Wh + r * ldh + (int64_t)h * f_head;
+    const T *a = att + (int64_t)h * 2 * f_head;
+    float p1 = 0.0f, p2 = 0.0f;
+    for (int i = 0; i < f_head; ++i) {
+        const float v = Elem<T>::to_f32(w[i]);
+        p1 = __builtin_fmaf(v, Elem<T>::to_f32(a[i]), p1);
+        p2 = __builtin_fmaf(v, Elem<T>::to_f32(a[f_head + i]), p2);
+    }
+    s1[gid] = p1;
+    s2[gid] = p2;
+}
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
+    int n_rows, int n_cols, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes,
+    unsigned ld_bytes, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
+    T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
+    const float *__restrict__ fill, int share)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int TILE = LPR * VEC;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int64_t r = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
+    const bool live = r < n_rows;
+    int e0 = 0, e1 = 0;
+    if (live) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    const float uniform = 1.0f / (float)n_cols;
+
+    for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+        const int col0 = c0 + sub * VEC;
+        const bool mine = col0 < n_feat;
+        const int h = mine ? col0 / f_head : 0;
+        const unsigned col_off = mine ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        const float si = (live && mine) ? s1[r * n_heads + h] : 0.0f;
+        const bool writer = mine && (col0 % f_head == 0);          // one lane per (row, head) writes E / S
+
+        // pass 1: the softmax state of this lane's head over all edges of the row.  The `share` lanes that
+        // hold one head (a power of two, adjacent) take every share-th edge each and merge their states.
+        float m = -INFINITY, l = 0.0f;
+        for (int base = e0; base < e1; base += LPR) {
+            const int idx = base + sub;
+            int c = 0, pos = 0;
+            if (idx < e1) { c = col[idx]; pos = Elem<T>::to_f32(val[idx]) > 0.0f; }
+            const int n = e1 - base < LPR ? e1 - base : LPR;
+            for (int t0 = 0; t0 < n; t0 += share) {
+                const int t = t0 + (sub & (share - 1));
+                const int cc = __shfl(c, t, LPR);
+                const int pp = __shfl(pos, t, LPR);
+                if (t < n && pp && mine) softmax_merge(m, l, leaky(si + s2[(int64_t)cc * n_heads + h], alpha), 1.0f);
+            }
+        }
+        for (int off = 1; off < share; off <<= 1) {
+            const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+            softmax_merge(m, l, m2, l2);
+        }
+        const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+        const bool dead = live && mine && !(l > 0.0f) && fill != nullptr;
+
+        // pass 2: weighted gather
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        for (int base = e0; base < e1; base += LPR) {
+            const int idx = base + sub;
+            int c = 0, pos = 0;
+            if (idx < e1) { c = col[idx]; pos = Elem<T>::to_f32(val[idx]) > 0.0f; }
+            const int n = e1 - base < LPR ? e1 - base : LPR;
+            for (int t = 0; t < n; ++t) {
+                const int cc = __shfl(c, t, LPR);
+                const int pp = __shfl(pos, t, LPR);
+                float x = 0.0f, p = 0.0f;
+                if (mine) {
+                    x = leaky(si + s2[(int64_t)cc * n_heads + h], alpha);
+                    if (pp) p = expf(x - m) * inv_l;
+                }
+                if (writer) {
+                    const int64_t o = (int64_t)(base + t) * n_heads + h;
+                    if (E) E[o] = x;
+                    if (S) S[o] = dead ? uniform : p;
+                }
+                Gather<T, VEC>::run(acc, p, rsrc, mine ? (unsigned)cc * ld_bytes + col_off : kOOB);
+            }
+        }
+        if (live && mine) {
+            T out[VEC];
+            if (dead) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = (col0 + i < n_feat) ? fill[col0 + i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                T v = Elem<T>::from_f32(acc[i]);
+                out[i] = (!relu || v > (T)0) ? v : (T)0;
+            }
+            T *drow = D + r * ldd;
+            if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
+                *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (col0 + i < n_feat) drow[col0 + i] = out[i];
+            }
+        }
+    }
+}
+
 // Column means of Wh in two fixed-order stages: slab sums, then the slabs added in order.
 constexpr int kMeanSlabs = 512;
 
@@ -190,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void col_mean_finish_kernel(int n_rows, int
 }
 
 struct GatArgs {
-    int relu, n_rows, n_cols, n_feat;
+    int relu, n_rows, n_cols, n_feat, n_heads;
     float alpha;
     const int32_t *rowptr, *col;
     const void *val, *Wh, *att;
@@ -209,6 +338,25 @@ int gat_launch_one(const GatArgs &a)
     const int rows_per_block = (64 / LPR) * (kBlock / 64);
     const unsigned grid = (unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block);
     const unsigned grid_s = (unsigned)((a.n_cols + rows_per_block - 1) / rows_per_block);
+    if (a.n_heads > 1) {
+        const int f_head = a.n_feat / a.n_heads;
+        // lanes per head; they share the softmax pass when that is a power of two that divides the lane
+        // group and no head straddles a column tile (otherwise every lane walks all edges itself)
+        const int lanes_per_head = f_head / VEC;
+        const bool pow2 = lanes_per_head > 0 && (lanes_per_head & (lanes_per_head - 1)) == 0;
+        const int share = (f_head % VEC == 0 && pow2 && lanes_per_head <= LPR) ? lanes_per_head : 1;
+        float *h1 = a.s, *h2 = a.s + (size_t)a.n_cols * a.n_heads;
+        const int64_t pairs = (int64_t)a.n_cols * a.n_heads;
+        hipLaunchKernelGGL((gat_scores_heads_kernel<T>), dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           a.stream, a.n_cols, a.n_heads, f_head, (const T *)a.Wh, a.ldh, (const T *)a.att, h1, h2);
+        SGX_LAUNCH_CHECK();
+        hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows,
+                           a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
+                           a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill,
+                           share);
+        SGX_LAUNCH_CHECK();
+        return SGX_OK;
+    }
     float *s1 = a.s, *s2 = a.s + a.n_cols;                    // scores of every row of the table
     hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid_s), dim3(kBlock), 0, a.stream, a.n_cols, a.n_feat,
                        (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2, a.vec_ok);
@@ -236,20 +384,24 @@ int gat_launch_lpr(const GatArgs &a, int lpr)
 
 }  // namespace
 
-extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int fill_dead_rows)
+extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows)
 {
     if (n_cols < 0 || n_feat < 1) return 0;
-    size_t floats = (size_t)2 * n_cols;
+    if (n_heads < 1) n_heads = 1;
+    size_t floats = (size_t)2 * n_cols * n_heads;
     if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
     return sgx_align_up(floats * sizeof(float), 256);
 }
 
-extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, float alpha,
+extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads,
+                                 float alpha,
                                  const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                                  const void *Wh, int64_t ldh, const void *attention,
                                  void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream)
 {
+    if (n_heads < 1) n_heads = 1;
     if (n_rows < 0 || n_cols < n_rows || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
+    if (n_feat % n_heads != 0) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
     if (!rowPtr || !columnIndex || !values || !Wh || !attention || !D) return SGX_ERR_NULL;
     if (!s_scratch) return SGX_ERR_WORKSPACE;
@@ -258,13 +410,13 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
     const unsigned long long table_bytes = (unsigned long long)n_cols * (unsigned long long)ldh * es;
     if (table_bytes >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
     GatArgs a;
-    a.relu = relu; a.n_rows = n_rows; a.n_cols = n_cols; a.n_feat = n_feat; a.alpha = alpha;
+    a.relu = relu; a.n_rows = n_rows; a.n_cols = n_cols; a.n_feat = n_feat; a.n_heads = n_heads; a.alpha = alpha;
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
     a.fill = nullptr;
     if (fill_dead_rows) {
-        float *partial = s_scratch + (size_t)2 * n_cols, *mean = partial + (size_t)kMeanSlabs * n_feat;
+        float *partial = s_scratch + (size_t)2 * n_cols * n_heads, *mean = partial + (size_t)kMeanSlabs * n_feat;
         if (dtype == SGX_F16)
             hipLaunchKernelGGL(col_sum_slab_kernel<f16>, dim3(kMeanSlabs), dim3(kBlock), 0, a.stream, n_cols, n_feat,
                                (const f16 *)Wh, ldh, partial);
@@ -280,6 +432,7 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
     a.vec_ok = ((uintptr_t)Wh % 16 == 0) && ((ldh * es) % 16 == 0);
     a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
     const int per16 = (int)(16 / es);
+    if (n_heads > 1 && (n_feat / n_heads) % per16 != 0) a.vec_ok = 0;      // a lane's 16 bytes must stay inside one head
     if (a.vec_ok) {
         int lpr = sgx_next_pow2((n_feat + per16 - 1) / per16);
         if (lpr > 64) lpr = 64;

@@ -255,7 +255,8 @@ def transpose(x, ldo=None):
 
 def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
                   acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None,
-                  quant=None, adj_quantized=False, cache_quantized_adj=True, fea_threads=1, adj_threads=1):
+                  quant=None, adj_quantized=False, cache_quantized_adj=True, fea_threads=1, adj_threads=1,
+                  gat_heads=1):
     """One fused layer  D = act(A . (X . W))  through sgx_layer_forward.
 
     adj : Csr [N, M_adj];  fea : Csr [M_adj, M_fea] (gemm_mode 0) or dense tensor (gemm_mode 1);
@@ -308,9 +309,13 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
         if att.numel() != 2 * P or att.dtype != Wt.dtype:
             raise ValueError("attention must hold 2*P_w elements of the layer dtype")
         d.attention, d.alpha = att.data_ptr(), float(alpha)
+        if P % int(gat_heads):
+            raise ValueError("P_w must be a multiple of gat_heads")
+        d.gat_heads = int(gat_heads)
         if want_edge_outputs:
-            E = torch.empty(adj.nnz, dtype=torch.float32, device=Wt.device)
-            S = torch.empty(adj.nnz, dtype=torch.float32, device=Wt.device)
+            es_shape = (adj.nnz,) if gat_heads == 1 else (adj.nnz, int(gat_heads))
+            E = torch.empty(es_shape, dtype=torch.float32, device=Wt.device)
+            S = torch.empty(es_shape, dtype=torch.float32, device=Wt.device)
             d.E, d.S = E.data_ptr(), S.data_ptr()
     if agg_events is not None:          # (begin, end) hipEvent_t handles, see hipevents.py
         d.ev_agg_begin, d.ev_agg_end = agg_events
@@ -346,8 +351,10 @@ def requantize_(H, scale_fea, internal_bits):
     return H
 
 
-def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False, fill_dead_rows=None, out=None):
+def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False, fill_dead_rows=None, out=None,
+                  heads=1):
     """Edge-softmax aggregate over an already computed Wh [adj.n_cols, F]; row r of adj is node r of Wh.
+    heads > 1: F/heads columns per head, attention = heads vectors of 2*F/heads (E, S become [nnz, heads]).
     fill_dead_rows: None = decide from the adjacency (rows without a positive entry get the mean of
     all rows of Wh, as in the reference's dense emulation), False = such rows give 0."""
     _dev2d(Wh, "Wh")
@@ -359,12 +366,16 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
     if out is None:
         out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
     E = S = None
+    heads = int(heads)
+    if F % heads or att.numel() != 2 * F:
+        raise ValueError("F must be a multiple of heads and attention must hold 2*F elements")
     if want_edge_outputs:
-        E = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
-        S = torch.empty(adj.nnz, dtype=torch.float32, device=Wh.device)
+        es_shape = (adj.nnz,) if heads == 1 else (adj.nnz, heads)
+        E = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
+        S = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
     fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
-    s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, fill) // 4, dtype=torch.float32, device=Wh.device)
-    check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
+    s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, fill) // 4, dtype=torch.float32, device=Wh.device)
+    check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, heads, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
                                 _ptr(E), _ptr(S), _ptr(s), _stream()), "sgx_gat_aggregate")
     return (out, E, S) if want_edge_outputs else out

@@ -256,6 +256,54 @@ def test_gat_aggregate(sgx, oracle, dtype, F):
         assert (gS.cpu().numpy()[va <= 0] == 0).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("heads,f_head", [(8, 32), (4, 12), (2, 64), (3, 5)])
+def test_gat_multi_head_is_the_single_head_formula_per_slice(sgx, oracle, dtype, heads, f_head):
+    """n_heads > 1 = the reference's single-head formula on each column slice with its own attention
+    vector (the oracle's gat_f64 per slice), concatenated; also against the kernel's own single-head runs."""
+    rng = np.random.default_rng(heads * 100 + f_head)
+    n, F = 403, heads * f_head
+    rp, ci, va = _rand_csr(rng, n, n, 9.0, empty_frac=0.0)
+    dense = _dense(rp, ci, np.abs(va) + 0.1, n, n)
+    dense[np.arange(n), np.arange(n)] = 1.0
+    dense[rng.random((n, n)) < 0.003] = -0.5
+    dense[11, :] = 0                                         # a row without any edge
+    rows, cols = np.nonzero(dense)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    va = dense[rows, cols].astype(np.float32)
+    Wh = rng.standard_normal((n, F)).astype(np.float32)
+    att = (rng.standard_normal((heads, 2 * f_head)) * 0.3).astype(np.float32)
+    if dtype == torch.float16:
+        va, Wh, att = _h(oracle, va), _h(oracle, Wh), _h(oracle, att)
+    csr = (rp, cols.astype(np.int32), va)
+    A = _csr(sgx, csr, n, dtype)
+    got, gE, gS = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, want_edge_outputs=True,
+                                    heads=heads, fill_dead_rows=False)
+    assert gE.shape == (len(va), heads) and gS.shape == (len(va), heads)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-6)
+    for h in range(heads):
+        sl = slice(h * f_head, (h + 1) * f_head)
+        D, E, S = oracle.gat_f64(1, csr, np.ascontiguousarray(Wh[:, sl]), att[h], 0.2)
+        np.testing.assert_allclose(got[:, sl].float().cpu().numpy(), D, **tol)
+        np.testing.assert_allclose(gE[:, h].cpu().numpy(), E, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gS[:, h].cpu().numpy(), S, rtol=1e-4, atol=1e-6)
+        one = sgx.gat_aggregate(A, _dev(np.ascontiguousarray(Wh[:, sl]), dtype), _dev(att[h], dtype), relu=1,
+                                fill_dead_rows=False)
+        np.testing.assert_allclose(got[:, sl].float().cpu().numpy(), one.float().cpu().numpy(), rtol=tol["rtol"],
+                                   atol=max(tol["atol"], 1e-5))      # two fp32 orders of the same sums
+    assert (got[11] == 0).all()
+    # rows without a live edge, dense-emulation rule: the mean of all rows of Wh, per column
+    filled = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=0, heads=heads)
+    np.testing.assert_allclose(filled[11].float().cpu().numpy(), Wh.mean(0), **tol)
+    # through the layer entry point: X = I makes X.W = Wh exactly
+    X = torch.eye(n, dtype=dtype, device="cuda")
+    out = sgx.layer_forward(A, X, _dev(np.ascontiguousarray(Wh.T), dtype), relu=1,
+                            gat_attention=_dev(att.reshape(-1), dtype), gat_heads=heads)
+    ref = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads)
+    assert torch.equal(out, ref)
+
+
 def test_gat_layer_through_desc(sgx, oracle):
     d = load("cora")
     rng = np.random.default_rng(3)
