@@ -150,6 +150,10 @@ got2 = D.layer_halo(backend, A_all, X, Wt, True, plan2)
 table = torch.cat([H, H.index_select(0, send_rows)])
 assert torch.equal(got2, ops.spmm(A_all, table, relu=True))
 assert torch.allclose(got2.float(), want.float(), rtol=2e-3, atol=2e-3)
+# the index exchange of build_halo_plan on RCCL (int64 device tensors, equal and empty splits)
+auto = D.build_halo_plan(A_own.col, [0, n], 0)
+assert auto.n_own == n and auto.recv_counts == [0] and auto.send_counts == [0]
+assert torch.equal(auto.col_compact, A_own.col)
 got3 = D.layer_allgather(backend, A_own, X, Wt, True, [0, n])
 assert torch.equal(got3, ops.spmm(A_own, H, relu=True))
 torch.cuda.synchronize()
