@@ -211,3 +211,42 @@ def test_mutag_training_reaches_reference_accuracy():
         best = max(best, float((pred == test.y).float().mean()))
     assert losses[-1] < losses[0]
     assert best >= 0.72, best
+
+
+def test_two_layer_forward_replayed_from_a_hipgraph(oracle):
+    """The launches of a forward pass captured once and replayed with new input values (sparse first
+    layer, dense second, GAT third): same bits as the eager calls."""
+    import numpy as np
+    from _fixtures import GOLD, load
+    from sgracex1_amd import graphs, ops
+    from sgracex1_amd.graphed import Graphed
+    d = load("cora")
+    dev = torch.device("cuda")
+    w2 = np.load(os.path.join(GOLD, "cora.npz"))["w2"].astype(np.float32)
+    A = graphs.csr_from_numpy(*d["adj"], d["N"])
+    X = graphs.csr_from_numpy(*d["fea"], d["M_fea"])
+    A.plan, X.plan
+    W1t = torch.as_tensor(d["Wt"], device=dev).half()
+    W2t = torch.as_tensor(np.ascontiguousarray(w2.T), device=dev).half()
+    att = (torch.rand(2 * W2t.shape[0], device=dev) - 0.5).half()
+    D1 = torch.empty((A.n_rows, W1t.shape[0]), dtype=torch.float16, device=dev)
+    D2 = torch.empty((A.n_rows, W2t.shape[0]), dtype=torch.float16, device=dev)
+    D3 = torch.empty_like(D2)
+
+    def forward():
+        ops.layer_forward(A, X, W1t, relu=True, out=D1)
+        ops.layer_forward(A, D1, W2t, relu=False, out=D2)
+        ops.layer_forward(A, D1, W2t, relu=True, gat_attention=att, out=D3)
+        return D2
+
+    run = Graphed(forward)
+    for scale in (1.0, 0.5, -2.0):
+        X.val.copy_(torch.as_tensor(d["fea"][2], device=dev).half() * scale)      # new values, same buffers
+        D1.zero_(), D2.zero_(), D3.zero_()
+        out = run()
+        torch.cuda.synchronize()
+        got = (D1.clone(), out.clone(), D3.clone())
+        forward()
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], D1) and torch.equal(got[1], D2) and torch.equal(got[2], D3)
+        assert D2.abs().max() > 0
