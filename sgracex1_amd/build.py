@@ -54,5 +54,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+TESTBENCH_SRC = os.path.join(ROOT, "examples", "sgx_testbench.cpp")
+TESTBENCH = os.path.join(ROOT, "examples", "sgx_testbench")
+
+
+def build_testbench(force=False, verbose=False):
+    """examples/sgx_testbench: the C++ host that binds only include/sgx.h (the role of the reference's
+    main_float.cpp).  Linked against the in-tree libsgx.so with a relative rpath."""
+    build(force=False)
+    if (not force and os.path.exists(TESTBENCH)
+            and os.path.getmtime(TESTBENCH) >= max(os.path.getmtime(TESTBENCH_SRC), os.path.getmtime(LIB))):
+        return TESTBENCH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), TESTBENCH_SRC, "-L", CSRC, "-lsgx",
+           "-Wl,-rpath,$ORIGIN/../sgracex1_amd/csrc", "-o", TESTBENCH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TESTBENCH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_testbench(force="--force" in sys.argv, verbose=True))
