@@ -241,13 +241,16 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
  * (the per-node scores Wh.a1, Wh.a2 and the column-mean partials).  E/S optional [nnz] fp32.
  * n_heads > 1 (BASELINE config 5; the reference itself has one head, SG.py:1176-1178): the formula
  * above on each slice of n_feat / n_heads columns with its own vector attention[h][0 : 2*F_head],
- * outputs concatenated -- what n_heads single-head calls on the slices give; E/S are [nnz][n_heads]. */
-size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows);
+ * outputs concatenated -- what n_heads single-head calls on the slices give; E/S are [nnz][n_heads].
+ * plan (optional): rows it marks long are cut into edge chunks with running softmax states that are
+ * merged in a fixed order (single head; with several heads the plan is ignored). */
+size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan);
 int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads,
                       float alpha,
                       const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                       const void *Wh, int64_t ldh, const void *attention,
-                      void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream);
+                      void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan, float *s_scratch,
+                      void *stream);
 
 /* ---- helpers on either side of the path (SURVEY 8f "next" rows) -------------------- */
 

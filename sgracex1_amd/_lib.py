@@ -114,10 +114,10 @@ def _load():
     lib.sgx_xw_sparse.restype = c_int
     lib.sgx_transpose.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp]
     lib.sgx_transpose.restype = c_int
-    lib.sgx_gat_scratch_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.sgx_gat_scratch_bytes.argtypes = [c_int, c_int, c_int, c_int, vp]
     lib.sgx_gat_scratch_bytes.restype = sz
     lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
-                                      vp, c_i64, vp, vp, vp, vp]
+                                      vp, c_i64, vp, vp, vp, vp, vp]
     lib.sgx_gat_aggregate.restype = c_int
     lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]
     lib.sgx_csr_validate.restype = c_int

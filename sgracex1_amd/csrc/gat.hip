@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
     T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
-    const float *__restrict__ fill)
+    const float *__restrict__ fill, int long_threshold)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -83,10 +83,11 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     const int64_t r = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
-    const bool live = r < n_rows;
+    bool live = r < n_rows;
     int e0 = 0, e1 = 0;
     float si = 0.0f;
     if (live) { e0 = rowptr[r]; e1 = rowptr[r + 1]; si = s1[r]; }
+    if (live && long_threshold > 0 && e1 - e0 > long_threshold) { live = false; e1 = e0; }   // the split path owns it
 
     // pass 1: running max and sum of exp over the row's positive edges
     float m = -INFINITY, l = 0.0f;
@@ -159,6 +160,143 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
                     if (col0 + i < n_feat) drow[col0 + i] = out[i];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Long rows (sgx_plan): a hub row of a power-law graph would keep one lane group busy for
+// thousands of dependent steps.  Its edges are cut into the plan's 512-edge tasks; one wavefront
+// per task keeps a running (max, sum, weighted row sum) per lane group -- rescaled once per piece
+// of LPR edges -- and merges its groups; the tasks of a row are then merged in task order
+// (m = max m_t, l = sum l_t e^(m_t - m), row = sum acc_t e^(m_t - m) / l): the same softmax, and
+// the same bits from run to run.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float rescale_factor(float m_old, float m_new)
+{
+    return m_old == -INFINITY ? 0.0f : expf(m_old - m_new);        // (-inf) - (-inf) never reaches expf
+}
+
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_split_kernel(
+    int n_tasks, int n_feat, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
+    const int32_t *__restrict__ task_e1, const int32_t *__restrict__ col, const T *__restrict__ val,
+    const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes, const float *__restrict__ s1,
+    const float *__restrict__ s2, float alpha, float *__restrict__ E, float *__restrict__ pacc, int ldp,
+    float *__restrict__ pm, float *__restrict__ pl)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int TILE = LPR * VEC;
+    const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
+    const int te0 = task_e0[task], te1 = task_e1[task];
+    const float si = s1[task_row[task]];
+
+    for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+        const int col0 = c0 + sub * VEC;
+        const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        float m = -INFINITY, l = 0.0f;             // l: this lane's share of the group's sum
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        for (int base = te0 + grp * LPR; base < te1; base += RPW * LPR) {
+            const int idx = base + sub;
+            int c = 0;
+            float x = -INFINITY;
+            if (idx < te1) {
+                c = col[idx];
+                const float xe = leaky(si + s2[c], alpha);
+                if (E && c0 == 0) E[idx] = xe;
+                if (Elem<T>::to_f32(val[idx]) > 0.0f) x = xe;
+            }
+            float pmax = x;
+#pragma unroll
+            for (int off = 1; off < LPR; off <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off));
+            if (pmax == -INFINITY) continue;        // no live edge in this piece (uniform across the group)
+            const float m_new = fmaxf(m, pmax);
+            const float scale = rescale_factor(m, m_new);
+            const float p = x == -INFINITY ? 0.0f : expf(x - m_new);
+            m = m_new;
+            l = l * scale + p;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] *= scale;
+            const int n = te1 - base < LPR ? te1 - base : LPR;
+            for (int t = 0; t < n; ++t) {
+                const int cc = __shfl(c, t, LPR);
+                const float pp = __shfl(p, t, LPR);
+                Gather<T, VEC>::run(acc, pp, rsrc, col_off != kOOB ? (unsigned)cc * ld_bytes + col_off : kOOB);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) l += __shfl_xor(l, off);        // the group's sum
+        // merge the lane groups of the wavefront (fixed tree order)
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+            const float mn = fmaxf(m, m2);
+            const float a = rescale_factor(m, mn), b = rescale_factor(m2, mn);
+            l = l * a + l2 * b;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = acc[i] * a + __shfl_xor(acc[i], off) * b;
+            m = mn;
+        }
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (col0 + i < n_feat) pacc[(int64_t)task * ldp + col0 + i] = acc[i];
+            if (sub == 0 && c0 == 0) { pm[task] = m; pl[task] = l; }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_split_finalize_kernel(
+    int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
+    const float *__restrict__ pacc, int ldp, const float *__restrict__ pm, const float *__restrict__ pl,
+    T *__restrict__ D, int64_t ldd, int relu, const float *__restrict__ fill, float *__restrict__ row_m,
+    float *__restrict__ row_l)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)n_long * n_feat) return;
+    const int i = (int)(gid / n_feat), j = (int)(gid % n_feat);
+    const int t0 = long_first[i], t1 = long_first[i + 1];
+    float m = -INFINITY;
+    for (int t = t0; t < t1; ++t) m = fmaxf(m, pm[t]);
+    float l = 0.0f, a = 0.0f;
+    for (int t = t0; t < t1; ++t) {
+        const float w = rescale_factor(pm[t], m);
+        l += pl[t] * w;
+        a += pacc[(int64_t)t * ldp + j] * w;
+    }
+    float out = l > 0.0f ? a / l : (fill ? fill[j] : 0.0f);
+    T v = Elem<T>::from_f32(out);
+    D[(int64_t)long_row[i] * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
+    if (j == 0) { row_m[i] = m; row_l[i] = l; }
+}
+
+// softmax values of the long rows' edges, once the rows' (max, sum) are known: workgroup (i, y) walks
+// every gridDim.y-th 256-edge piece of long row i
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_split_softmax_kernel(
+    int n_cols, const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const T *__restrict__ val, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
+    const float *__restrict__ row_m, const float *__restrict__ row_l, int filled, float *__restrict__ S)
+{
+    const int i = blockIdx.x;
+    const int row = long_row[i];
+    const float m = row_m[i], l = row_l[i], si = s1[row];
+    const int e1 = rowptr[row + 1];
+    for (int idx = rowptr[row] + blockIdx.y * kBlock + threadIdx.x; idx < e1; idx += gridDim.y * kBlock) {
+        float p = 0.0f;
+        if (l > 0.0f) {
+            if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(leaky(si + s2[col[idx]], alpha) - m) / l;
+        } else if (filled) {
+            p = 1.0f / (float)n_cols;
+        }
+        S[idx] = p;
     }
 }
 
@@ -328,6 +466,8 @@ struct GatArgs {
     void *D;
     float *E, *S, *s;
     const float *fill;
+    const sgx_plan *plan;      // long rows -> split path (single head only)
+    float *split;              // scratch of the split path, behind the scores / column means
     int vec_ok, vec_store;
     hipStream_t stream;
 };
@@ -361,9 +501,31 @@ int gat_launch_one(const GatArgs &a)
     hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid_s), dim3(kBlock), 0, a.stream, a.n_cols, a.n_feat,
                        (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2, a.vec_ok);
     SGX_LAUNCH_CHECK();
+    const sgx_plan *p = a.plan;
+    const int long_thr = (p && p->n_long > 0) ? p->long_threshold : 0;
+    if (long_thr > 0) {
+        const int ldp = (int)sgx_align_up((size_t)a.n_feat, 4);
+        float *pacc = a.split, *pm = pacc + (size_t)p->n_tasks * ldp, *pl = pm + p->n_tasks;
+        float *row_m = pl + p->n_tasks, *row_l = row_m + p->n_long;
+        hipLaunchKernelGGL((gat_split_kernel<T, VEC, LPR>), dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)),
+                           dim3(kBlock), 0, a.stream, p->n_tasks, a.n_feat, p->task_row, p->task_e0, p->task_e1, a.col,
+                           (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha, a.E, pacc, ldp, pm, pl);
+        SGX_LAUNCH_CHECK();
+        const int64_t total = (int64_t)p->n_long * a.n_feat;
+        hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, pacc, ldp, pm, pl, (T *)a.D, a.ldd,
+                           a.relu, a.fill, row_m, row_l);
+        SGX_LAUNCH_CHECK();
+        if (a.S) {
+            hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols,
+                               p->long_row, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, row_m, row_l,
+                               a.fill != nullptr, a.S);
+            SGX_LAUNCH_CHECK();
+        }
+    }
     hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_cols, a.n_feat,
                        a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
-                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill);
+                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill, long_thr);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -384,12 +546,23 @@ int gat_launch_lpr(const GatArgs &a, int lpr)
 
 }  // namespace
 
-extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows)
+namespace {
+size_t base_scratch_floats(int n_cols, int n_feat, int n_heads, int fill_dead_rows)
+{
+    size_t floats = (size_t)2 * n_cols * n_heads;
+    if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
+    return sgx_align_up(floats, 64);
+}
+bool uses_split(const sgx_plan *plan, int n_heads) { return plan && plan->n_long > 0 && n_heads == 1; }
+}  // namespace
+
+extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan)
 {
     if (n_cols < 0 || n_feat < 1) return 0;
     if (n_heads < 1) n_heads = 1;
-    size_t floats = (size_t)2 * n_cols * n_heads;
-    if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
+    size_t floats = base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
+    if (uses_split(plan, n_heads))        // per task: fp32 partial row + (max, sum); per long row: (max, sum)
+        floats += (size_t)plan->n_tasks * (sgx_align_up((size_t)n_feat, 4) + 2) + (size_t)2 * plan->n_long;
     return sgx_align_up(floats * sizeof(float), 256);
 }
 
@@ -397,9 +570,11 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
                                  float alpha,
                                  const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                                  const void *Wh, int64_t ldh, const void *attention,
-                                 void *D, int64_t ldd, float *E, float *S, float *s_scratch, void *stream)
+                                 void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan, float *s_scratch,
+                                 void *stream)
 {
     if (n_heads < 1) n_heads = 1;
+    if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
     if (n_rows < 0 || n_cols < n_rows || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
     if (n_feat % n_heads != 0) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
@@ -415,6 +590,8 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
     a.fill = nullptr;
+    a.plan = uses_split(plan, n_heads) ? plan : nullptr;
+    a.split = s_scratch + base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
     if (fill_dead_rows) {
         float *partial = s_scratch + (size_t)2 * n_cols * n_heads, *mean = partial + (size_t)kMeanSlabs * n_feat;
         if (dtype == SGX_F16)

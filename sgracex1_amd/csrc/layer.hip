@@ -30,7 +30,7 @@ Carve carve(const sgx_layer_desc *d)
     size_t s1 = sgx_spmm_scratch_bytes(d->plan_adj, d->P_w);
     size_t s2 = d->gemm_mode == 0 ? sgx_spmm_scratch_bytes(d->plan_fea, d->P_w) : 0;
     c.s_off = off; c.s_bytes = s1 > s2 ? s1 : s2; off += c.s_bytes;
-    c.g_off = off; c.g_bytes = d->gat_mode ? sgx_gat_scratch_bytes(d->M_adj, d->P_w, d->gat_heads, d->gat_fill_dead_rows) : 0; off += c.g_bytes;
+    c.g_off = off; c.g_bytes = d->gat_mode ? sgx_gat_scratch_bytes(d->M_adj, d->P_w, d->gat_heads, d->gat_fill_dead_rows, d->plan_adj) : 0; off += c.g_bytes;
     c.q_off = off; c.q_bytes = 0; c.qb = c.qx = c.qa = c.qt = 0;
     if (d->quant) {
         const sgx_quant *q = d->quant;
@@ -166,7 +166,7 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         if (!attention) return SGX_ERR_NULL;
         rc = sgx_gat_aggregate(d->dtype, d->relu, d->gat_fill_dead_rows, d->N_adj, d->M_adj, d->P_w, d->gat_heads, d->alpha,
                                d->rowPtr_adj, d->columnIndex_adj,
-                               values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S,
+                               values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S, d->plan_adj,
                                (float *)(ws + c.g_off), s);
     } else {
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,

@@ -352,7 +352,7 @@ def requantize_(H, scale_fea, internal_bits):
 
 
 def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False, fill_dead_rows=None, out=None,
-                  heads=1):
+                  heads=1, use_plan=True):
     """Edge-softmax aggregate over an already computed Wh [adj.n_cols, F]; row r of adj is node r of Wh.
     heads > 1: F/heads columns per head, attention = heads vectors of 2*F/heads (E, S become [nnz, heads]).
     fill_dead_rows: None = decide from the adjacency (rows without a positive entry get the mean of
@@ -374,10 +374,11 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
         E = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
         S = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
     fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
-    s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, fill) // 4, dtype=torch.float32, device=Wh.device)
+    plan = adj.plan.handle if (use_plan and adj.wants_plan) else None
+    s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, fill, plan) // 4, dtype=torch.float32, device=Wh.device)
     check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, heads, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
-                                _ptr(E), _ptr(S), _ptr(s), _stream()), "sgx_gat_aggregate")
+                                _ptr(E), _ptr(S), plan, _ptr(s), _stream()), "sgx_gat_aggregate")
     return (out, E, S) if want_edge_outputs else out
 
 

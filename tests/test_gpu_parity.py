@@ -304,6 +304,50 @@ def test_gat_multi_head_is_the_single_head_formula_per_slice(sgx, oracle, dtype,
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("F", [64, 256, 20])
+def test_gat_long_rows_take_the_split_path(sgx, oracle, dtype, F):
+    """Hub rows (> 512 edges) are cut into tasks with running softmax states merged in a fixed order:
+    same result as the oracle and as the unsplit kernel, E / S included, a fully masked hub row too."""
+    rng = np.random.default_rng(F)
+    n = 3000
+    rp, ci, va = _rand_csr(rng, n, n, 6.0, empty_frac=0.0)
+    dense = _dense(rp, ci, np.abs(va) + 0.1, n, n)
+    dense[np.arange(n), np.arange(n)] = 1.0
+    for r, k, sign in ((5, 2500, 1.0), (77, 1200, 1.0), (1500, 800, -1.0), (2999, 513, 1.0)):
+        cols = rng.choice(n, k, replace=False)
+        dense[r, :] = 0
+        dense[r, cols] = sign * (rng.random(k) + 0.05)
+    dense[5, rng.choice(n, 300, replace=False)] *= -1                     # masked edges inside a hub row
+    rows, cols = np.nonzero(dense)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    va = dense[rows, cols].astype(np.float32)
+    Wh = rng.standard_normal((n, F)).astype(np.float32)
+    att = (rng.standard_normal(2 * F) * (0.6 / np.sqrt(F))).astype(np.float32)
+    if dtype == torch.float16:
+        va, Wh, att = _h(oracle, va), _h(oracle, Wh), _h(oracle, att)
+    csr = (rp, cols.astype(np.int32), va)
+    D, E, S = oracle.gat_f64(1, csr, Wh, att, 0.2)
+    A = _csr(sgx, csr, n, dtype)
+    assert A.plan.long_rows == 4
+    got, gE, gS = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, want_edge_outputs=True,
+                                    fill_dead_rows=False)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(got.float().cpu().numpy(), D, **tol)
+    np.testing.assert_allclose(gE.cpu().numpy(), E, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gS.cpu().numpy(), S, rtol=2e-4, atol=1e-7)
+    assert (got[1500] == 0).all() and abs(float(gS[rp[5]:rp[6]].sum()) - 1.0) < 1e-4
+    plain, pE, pS = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, want_edge_outputs=True,
+                                      fill_dead_rows=False, use_plan=False)
+    np.testing.assert_allclose(got.float().cpu().numpy(), plain.float().cpu().numpy(), **tol)
+    assert torch.equal(gE, pE)
+    again = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, fill_dead_rows=False)
+    assert torch.equal(again, got)                                         # fixed merge order: same bits every run
+    filled = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=0)          # dense-emulation rule for the masked hub
+    np.testing.assert_allclose(filled[1500].float().cpu().numpy(), Wh.mean(0), **tol)
+
+
 def test_gat_layer_through_desc(sgx, oracle):
     d = load("cora")
     rng = np.random.default_rng(3)

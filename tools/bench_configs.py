@@ -179,6 +179,20 @@ def main():
                 "nheads only widens W); ms_layer_8_heads: 8 independent softmaxes of 32 columns",
                 "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9})
 
+    if "c5" in want:
+        # the same layer on a power-law graph (R-MAT, 2^18 nodes): hub rows take the split path of the plan
+        n, P = 1 << 18, 256
+        A = graphs.rmat_graph(18, 2_330_000, seed=6)
+        Wh = torch.rand((n, P), generator=gen, device=dev).half()
+        att = ((torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.05).half()
+        A.plan
+        deg = (A.rowptr[1:] - A.rowptr[:-1])
+        t_split = timed(lambda: ops.gat_aggregate(A, Wh, att, relu=True), 50)
+        t_plain = timed(lambda: ops.gat_aggregate(A, Wh, att, relu=True, use_plan=False), 20)
+        report("c5 power-law variant: GAT aggregate, R-MAT 2^18 nodes", A,
+               {"ms_gat_aggregate": t_split, "ms_gat_aggregate_without_plan": t_plain},
+               {"width": P, "max_degree": int(deg.max()), "long_rows": A.plan.long_rows})
+
 
 if __name__ == "__main__":
     main()
