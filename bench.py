@@ -303,7 +303,7 @@ def main():
     b_min = nnz * (4 + es) + (n + 1) * 4 + (n + n_cols) * hidden * es          # compulsory traffic
     achieved = b_alg / (agg_avg_ms * 1e-3) / 1e9
     traffic = None
-    if os.path.exists(args.traffic_file):
+    if world == 1 and os.path.exists(args.traffic_file):        # PMC bytes were collected on the one-GPU launch
         try:
             tf = json.load(open(args.traffic_file))
             if tf.get("workload") == args.workload:
