@@ -74,8 +74,11 @@ typedef struct sgx_plan sgx_plan;
 int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
                     void *stream);
 void sgx_plan_destroy(sgx_plan *plan);
-/* number of rows that take the split path (for reports / tests) */
+/* number of rows that take the split path, and the edge count above which a row does (for reports /
+ * tests): 512, or 64 for matrices under 2^20 stored entries, whose run time is the longest row's
+ * chain of dependent steps */
 int sgx_plan_long_rows(const sgx_plan *plan);
+int sgx_plan_long_threshold(const sgx_plan *plan);
 /* share of lane-group steps that do work when 8 consecutive rows are packed per wavefront, and
  * whether the plan therefore schedules the short rows in degree order instead (1) or not (0) */
 float sgx_plan_natural_utilization(const sgx_plan *plan);

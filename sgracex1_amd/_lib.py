@@ -20,7 +20,7 @@ SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
-    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_natural_utilization",
+    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_long_threshold", "sgx_plan_natural_utilization",
     "sgx_plan_reordered",
     "sgx_fake_quantize", "sgx_requantize",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
@@ -87,6 +87,8 @@ def _load():
     lib.sgx_plan_destroy.restype = None
     lib.sgx_plan_long_rows.argtypes = [vp]
     lib.sgx_plan_long_rows.restype = c_int
+    lib.sgx_plan_long_threshold.argtypes = [vp]
+    lib.sgx_plan_long_threshold.restype = c_int
     lib.sgx_plan_natural_utilization.argtypes = [vp]
     lib.sgx_plan_natural_utilization.restype = ctypes.c_float
     lib.sgx_plan_reordered.argtypes = [vp]

@@ -157,6 +157,11 @@ extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_
 // ---------------------------------------------------------------------------------------
 static const int kLongThreshold = 512;   // rows with more edges than this take the split path
 static const int kChunk = 512;           // edges per split task (8 pieces of 64 edges per wavefront)
+// Small matrices finish in microseconds and their time IS the longest row's chain of dependent
+// steps (Cora: 168 edges = 21 steps on one lane group), so there rows are cut much earlier: a
+// 64-edge task is one step for every lane group of its wavefront.
+static const int64_t kSmallNnz = 1 << 20;
+static const int kSmallThreshold = 64, kSmallChunk = 64;
 static const float kReorderBelow = 0.7f; // natural-order lane-group utilisation below which rows are degree-ordered
 
 extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows, int n_feat_hint, void *stream)
@@ -169,23 +174,26 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
     SGX_HIP_CHECK(hipMemcpyAsync(rp.data(), rowPtr, sizeof(int32_t) * ((size_t)n_rows + 1), hipMemcpyDeviceToHost, s));
     SGX_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<int32_t> long_row, long_first, task_row, task_e0, task_e1;
+    const bool small = rp[(size_t)n_rows] < kSmallNnz;
+    const int long_threshold = small ? kSmallThreshold : kLongThreshold;
+    const int chunk = small ? kSmallChunk : kChunk;
     for (int r = 0; r < n_rows; ++r) {
         const int deg = rp[r + 1] - rp[r];
-        if (deg <= kLongThreshold) continue;
+        if (deg <= long_threshold) continue;
         long_row.push_back(r);
         long_first.push_back((int32_t)task_row.size());
-        for (int e = rp[r]; e < rp[r + 1]; e += kChunk) {
+        for (int e = rp[r]; e < rp[r + 1]; e += chunk) {
             task_row.push_back(r);
             task_e0.push_back(e);
-            task_e1.push_back(e + kChunk < rp[r + 1] ? e + kChunk : rp[r + 1]);
+            task_e1.push_back(e + chunk < rp[r + 1] ? e + chunk : rp[r + 1]);
         }
     }
     long_first.push_back((int32_t)task_row.size());
     sgx_plan *p = new sgx_plan();
     p->n_rows = n_rows;
     p->nnz = rp[(size_t)n_rows];
-    p->long_threshold = kLongThreshold;
-    p->chunk = kChunk;
+    p->long_threshold = long_threshold;
+    p->chunk = chunk;
     p->n_long = (int)long_row.size();
     p->n_tasks = (int)task_row.size();
     p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
@@ -211,13 +219,13 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
     p->row_order = nullptr;
     p->n_ordered = 0;
     {
-        const int kGroup = 8, kStepsMax = kLongThreshold / 8 + 1;
+        const int kGroup = 8, kStepsMax = long_threshold / 8 + 1;
         double useful = 0, spent = 0;
         for (int r0 = 0; r0 < n_rows; r0 += kGroup) {
             int mx = 0;
             for (int r = r0; r < r0 + kGroup && r < n_rows; ++r) {
                 const int deg = rp[r + 1] - rp[r];
-                const int steps = deg > kLongThreshold ? 0 : (deg + 7) / 8;
+                const int steps = deg > long_threshold ? 0 : (deg + 7) / 8;
                 useful += steps;
                 if (steps > mx) mx = steps;
             }
@@ -231,14 +239,14 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
             std::vector<int64_t> start(kStepsMax + 1, 0);
             for (int r = 0; r < n_rows; ++r) {
                 const int deg = rp[r + 1] - rp[r];
-                if (deg <= kLongThreshold) start[(deg + 7) / 8]++;
+                if (deg <= long_threshold) start[(deg + 7) / 8]++;
             }
             int64_t acc = 0;
             for (int b = kStepsMax; b >= 0; --b) { const int64_t c = start[b]; start[b] = acc; acc += c; }
             std::vector<int32_t> order((size_t)acc);
             for (int r = 0; r < n_rows; ++r) {
                 const int deg = rp[r + 1] - rp[r];
-                if (deg <= kLongThreshold) order[(size_t)start[(deg + 7) / 8]++] = r;
+                if (deg <= long_threshold) order[(size_t)start[(deg + 7) / 8]++] = r;
             }
             if (hipMalloc(&p->row_order, sizeof(int32_t) * order.size()) != hipSuccess ||
                 hipMemcpy(p->row_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -264,3 +272,4 @@ extern "C" float sgx_plan_natural_utilization(const sgx_plan *plan) { return pla
 extern "C" int sgx_plan_reordered(const sgx_plan *plan) { return plan && plan->row_order ? 1 : 0; }
 
 extern "C" int sgx_plan_long_rows(const sgx_plan *plan) { return plan ? plan->n_long : 0; }
+extern "C" int sgx_plan_long_threshold(const sgx_plan *plan) { return plan ? plan->long_threshold : 0; }

@@ -80,6 +80,10 @@ class Plan:
         return lib.sgx_plan_long_rows(self._h)
 
     @property
+    def long_threshold(self):
+        return lib.sgx_plan_long_threshold(self._h)
+
+    @property
     def natural_utilization(self):
         return lib.sgx_plan_natural_utilization(self._h)
 
@@ -142,7 +146,7 @@ class Csr:
     def wants_plan(self):
         """Building a plan costs one device->host copy and a stream sync; matrices this small finish
         in microseconds on any schedule, so they run without one unless a plan already exists."""
-        return self._plan is not None or self.nnz >= 65536
+        return self._plan is not None or self.nnz >= 8192
 
     def to(self, dtype):
         return self if self.val.dtype == dtype else Csr(self.rowptr, self.col, self.val.to(dtype), self.n_cols,

@@ -152,13 +152,14 @@ def test_spmm_long_rows_split_path(sgx, oracle, dtype):
         va, H = _h(oracle, va), _h(oracle, H)
     exact = _dense(rp, ci, va, n_rows, n_cols).astype(np.float64) @ H.astype(np.float64)
     A = _csr(sgx, (rp, ci, va), n_cols, dtype)
-    assert A.plan.long_rows == 3                                    # 513, 5000, 1500 (512 is not long)
+    # a small matrix (< 2^20 entries): rows over 64 edges are cut into 64-edge tasks (large ones: 512)
+    assert A.plan.long_threshold == 64 and A.plan.long_rows == 4
     with_plan = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=True).float().cpu().numpy()
     no_plan = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=False).float().cpu().numpy()
     tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(with_plan, exact, **tol)
     np.testing.assert_allclose(no_plan, exact, **tol)
-    short = np.diff(rp) <= 512
+    short = np.diff(rp) <= A.plan.long_threshold
     assert np.array_equal(with_plan[short], no_plan[short])         # untouched rows: same kernel, same bits
     again = sgx.spmm(A, _dev(H, dtype), relu=False, use_plan=True).float().cpu().numpy()
     assert np.array_equal(with_plan, again)                         # split sums are order-fixed
