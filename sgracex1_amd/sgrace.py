@@ -7,6 +7,7 @@
     Relu_SGRACE               SG.py:1142-1162
     GATConv_SGRACE            SG.py:1164-1260  forward(compute_attention, dense, relu, input,
                                                edge_index, norm, adj)
+    GAT_PYNQ                  demo/emulation/demo_sgrace.py:271-400 (the demo's two-layer model)
     init_SGRACE               SG.py:1271
 
 `config.acc == 1` runs the layer on the GPU through the C ABI (GCN aggregate or single-head GAT
@@ -128,7 +129,13 @@ class FPYNQ_GAT(torch.autograd.Function):
             Wt = weights.detach().t().to(dt).contiguous()
             fea = input.detach()
             if int(rm.gemm_mode) == 0:
-                fea = ops.Csr.from_dense(fea if fea.layout == torch.strided else fea.to_dense(), dt)
+                # the CSR of a feature matrix is rebuilt only when the tensor changes (node features are fixed
+                # over the epochs of a node-classification run)
+                key = (fea.data_ptr(), fea._version, tuple(fea.shape), dt)
+                if getattr(self, "_fea_key", None) != key:
+                    self._fea_csr = ops.Csr.from_dense(fea if fea.layout == torch.strided else fea.to_dense(), dt)
+                    self._fea_key = key
+                fea = self._fea_csr
             else:
                 fea = fea.to(dt).contiguous()
             my_ip.alpha = self.alpha
@@ -277,6 +284,35 @@ class GATConv_SGRACE(Module):
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class GAT_PYNQ(Module):
+    """The two-layer model of the SGRACE demo (demo/emulation/demo_sgrace.py:271-400), same call pattern:
+    sym_norm2 -> GATConv_SGRACE(compute_attention, dense=0, relu=1) -> Relu_SGRACE ->
+    GATConv_SGRACE(dense=1, relu=0) -> dropout -> Linear.  The demo reads the feature / class counts from
+    its global `dataset`; here they are constructor arguments."""
+
+    def __init__(self, num_node_features, hidden_channels, head_count, num_classes):
+        super(GAT_PYNQ, self).__init__()
+        self.att2 = GATConv_SGRACE(num_node_features, hidden_channels, head_count, dropout=0.1, alpha=0.2, concat=False)
+        self.conv22 = GATConv_SGRACE(hidden_channels * head_count, hidden_channels, 1)
+        self.reluh = Relu_SGRACE()
+        self.lin = torch.nn.Linear(hidden_channels, num_classes)
+        self._graph = None
+
+    def forward(self, x, edge_index):
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), x.size(0))
+        if self._graph is None or self._graph[0] != key:          # the graph is normalised once, not per call
+            ei, norm = sym_norm2(edge_index, x.size(0))
+            adj = _edge_csr(None, ei, norm, x.size(0), _torch_dtype()) if config.acc == 1 else \
+                torch.sparse_coo_tensor(ei, norm, (x.size(0), x.size(0)))
+            self._graph = (key, ei, norm, adj)
+        _, ei, norm, adj = self._graph
+        x = self.att2(config.compute_attention, 0, 1, x, ei, norm, adj)
+        x = self.reluh(x)
+        x = self.conv22(config.compute_attention, 1, 0, x, ei, norm, adj)
+        x = F.dropout(x.float(), p=0.5, training=self.training)
+        return self.lin(x)
 
 
 def init_SGRACE(device=None):

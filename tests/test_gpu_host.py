@@ -250,3 +250,39 @@ def test_two_layer_forward_replayed_from_a_hipgraph(oracle):
         torch.cuda.synchronize()
         assert torch.equal(got[0], D1) and torch.equal(got[1], D2) and torch.equal(got[2], D3)
         assert D2.abs().max() > 0
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("attention,qbits,floor", [(False, 32, 0.93), (True, 32, 0.93), (False, 8, 0.9), (True, 8, 0.9)])
+def test_sgrace_demo_model_trains_on_the_kernels(attention, qbits, floor):
+    """The demo's two-layer model (GAT_PYNQ) trained on a planted-partition graph with the layers on the
+    kernels: GCN and GAT aggregates, plain fp32 and the 8-bit quantised arithmetic."""
+    import importlib.util
+    from sgracex1_amd import config, sgrace
+    spec = importlib.util.spec_from_file_location("sgrace_nc", os.path.join(ROOT, "examples", "sgrace_node_classification.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type, config.device)
+    try:
+        res, model, (x, ei, _y) = mod.run(attention, qbits, epochs=60, acc=1, n=2000, verbose=False)
+        assert res["test_acc"] > floor, res
+        # the same weights through the reference's dense emulation (acc = 0)
+        model.eval()
+        with torch.no_grad():
+            on_gpu = model(x, ei).cpu()
+        config.acc, config.device = 0, "cpu"
+        sgrace.init_SGRACE()
+        twin = sgrace.GAT_PYNQ(x.shape[1], 16, 1, 5)
+        twin.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        twin.eval()
+        with torch.no_grad():
+            on_cpu = twin(x.cpu(), ei.cpu())
+        close = torch.isclose(on_gpu, on_cpu, rtol=1e-3, atol=1e-3)
+        assert close.float().mean() > (0.999 if qbits == 32 else 0.97), float((on_gpu - on_cpu).abs().max())
+        assert (on_gpu.argmax(1) == on_cpu.argmax(1)).float().mean() > 0.98
+    finally:
+        (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type,
+         config.device) = old
+        sgrace.init_SGRACE()
