@@ -276,6 +276,18 @@ size_t sgx_xt_g_workspace_bytes(int n_rows, int M, int P);
 int sgx_xt_g(int dtype_x, int n_rows, int M, int P, const void *X, int64_t ldx, const float *G, int64_t ldg,
              float *out, int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Edge pass of the GAT layer's backward (FPYNQ_GAT.backward, SG.py:884-1126, on the stored edges instead
+ * of dense N x N matrices): with E, S the forward's per-edge outputs, G = grad_output [n_rows][ldg] and
+ * Wh [n_cols][ldw], all fp32,
+ *   d_e = G[row e] . Wh[col e];  dx_e = S_e d_e;  sg_e = dx_e - S_e sum_row(dx);
+ *   sg_e = 0 where values[e] <= 0;  sg_e *= (E_e > 0 ? 1 : alpha)
+ * writes sg [nnz] and g1[r] = sum_row(sg).  The attention gradient is then [Wh^T g1 ; Wh^T g2] with
+ * g2 = the column sums of sg (row sums over A^T: sgx_spmm_csr) through sgx_xt_g. */
+int sgx_gat_backward_edges(int dtype_values, int n_rows, int n_cols, int n_feat, float alpha,
+                           const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                           const float *E, const float *S, const float *G, int64_t ldg, const float *Wh, int64_t ldw,
+                           float *sg, float *g1, void *stream);
+
 /* Readout + classifier head of the graph-classification model (MOL cell 18 tail) in one launch:
  * pooled[g][:] = mean of X rows [graph_ptr[g], graph_ptr[g+1])  (global_mean_pool over a sorted
  * `batch` vector), logits[g][c] = bias[c] + W[c][:] . pooled[g][:]  (torch Linear, W [C][F] fp32).

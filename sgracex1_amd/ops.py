@@ -367,6 +367,8 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
     if N != adj.n_cols or adj.n_rows > N:
         raise ValueError(f"Wh must have adj.n_cols = {adj.n_cols} rows (got {N}) and adj.n_rows <= adj.n_cols")
     att = _dev(attention, "attention").reshape(-1)
+    if adj.val.dtype != Wh.dtype or att.dtype != Wh.dtype:
+        raise TypeError("adjacency values, Wh and the attention vector must share one element type (MM.h:129-139)")
     if out is None:
         out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
     E = S = None
@@ -402,14 +404,37 @@ def xt_g(X, G):
     return out
 
 
-def csr_transpose(A):
-    """CSR of A^T (values kept, same dtype); features are fixed across epochs, so callers cache it."""
+def csr_transpose(A, return_order=False):
+    """CSR of A^T (values kept, same dtype); features are fixed across epochs, so callers cache it.
+    return_order: also the edge permutation (edge k of A^T is edge order[k] of A)."""
     row = torch.repeat_interleave(torch.arange(A.n_rows, device=A.col.device, dtype=torch.int64),
                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
     key = A.col.to(torch.int64) * A.n_rows + row
     order = torch.argsort(key)
-    return Csr.from_coo(A.col[order].contiguous(), row[order].to(torch.int32).contiguous(), A.val[order].contiguous(),
-                        A.n_cols, A.n_rows)
+    T = Csr.from_coo(A.col[order].contiguous(), row[order].to(torch.int32).contiguous(), A.val[order].contiguous(),
+                     A.n_cols, A.n_rows)
+    return (T, order) if return_order else T
+
+
+def gat_backward_edges(adj, E, S, G, Wh, alpha=0.2):
+    """Edge pass of FPYNQ_GAT.backward (sgx_gat_backward_edges): returns (sg [nnz], g1 [n_rows]) fp32."""
+    _dev2d(G, "G")
+    _dev2d(Wh, "Wh")
+    if G.dtype != torch.float32 or Wh.dtype != torch.float32 or E.dtype != torch.float32 or S.dtype != torch.float32:
+        raise TypeError("gat_backward_edges works on float32 E, S, G, Wh (the reference's backward is fp32)")
+    if Wh.shape[0] != adj.n_cols or G.shape != (adj.n_rows, Wh.shape[1]):
+        raise ValueError("G must be [adj.n_rows, F] and Wh [adj.n_cols, F]")
+    if Wh.stride(0) % 4 or Wh.data_ptr() % 16:           # rows are gathered 16 bytes at a time: pad them
+        padded = torch.zeros((Wh.shape[0], (Wh.shape[1] + 3) // 4 * 4), dtype=torch.float32, device=Wh.device)
+        padded[:, :Wh.shape[1]] = Wh
+        Wh = padded[:, :Wh.shape[1]]
+    sg = torch.empty(adj.nnz, dtype=torch.float32, device=G.device)
+    g1 = torch.empty(adj.n_rows, dtype=torch.float32, device=G.device)
+    check(lib.sgx_gat_backward_edges(dtype_code(adj.val.dtype), adj.n_rows, adj.n_cols, Wh.shape[1], float(alpha),
+                                     _ptr(adj.rowptr), _ptr(adj.col), _ptr(adj.val), _ptr(E.contiguous()), _ptr(S.contiguous()),
+                                     _ptr(G), G.stride(0), _ptr(Wh), Wh.stride(0), _ptr(sg), _ptr(g1), _stream()),
+          "sgx_gat_backward_edges")
+    return sg, g1
 
 
 def readout_mean_linear(x, graph_ptr, weight=None, bias=None, want_pooled=False):

@@ -207,19 +207,16 @@ class FPYNQ_GAT(torch.autograd.Function):
         if ctx.gat:
             E, S = saved[3], saved[4]
             P = ops.Csr(A.rowptr, A.col, S.contiguous(), A.n_cols, A._plan)       # attention matrix, fp32 values
-            Wh = input @ weights
-            row = torch.repeat_interleave(torch.arange(A.n_rows, device=g.device),
-                                          (A.rowptr[1:] - A.rowptr[:-1]).long())
-            col = A.col.long()
-            d_alpha = (g[row] * Wh[col]).sum(dim=1)                               # (g @ Wh^T) on the edges
-            dx = S * d_alpha
-            rs = torch.zeros(A.n_rows, device=g.device).index_add_(0, row, dx)
-            sg = dx - S * rs[row]
-            sg = torch.where(A.val.float() > 0, sg, torch.zeros_like(sg))
-            sg = torch.where(E > 0, sg, ctx.alpha * sg)
-            g1 = torch.zeros(A.n_rows, device=g.device).index_add_(0, row, sg)    # row sums of sg
-            g2 = torch.zeros(A.n_cols, device=g.device).index_add_(0, col, sg)    # column sums of sg
-            grad_attention = torch.cat([Wh.t() @ g1, Wh.t() @ g2]).unsqueeze(1)
+            Wh = ops.xw_dense(input.contiguous(), weights.t().contiguous())       # X . W, fp32 (SG.py:601); rows padded to 16 B
+            sg, g1 = ops.gat_backward_edges(A, E, S, g.contiguous(), Wh, ctx.alpha)
+            # column sums of sg = row sums over A^T; the transposed pattern is built once per graph
+            if getattr(A, "_transpose_pattern", None) is None:
+                A._transpose_pattern = ops.csr_transpose(A, return_order=True)
+            AT, order = A._transpose_pattern
+            ones = torch.ones((A.n_rows, 1), dtype=torch.float32, device=g.device)
+            g2 = ops.spmm(ops.Csr(AT.rowptr, AT.col, sg[order].contiguous(), AT.n_cols), ones, use_plan=False)
+            ga = ops.xt_g(Wh, torch.cat([g1.unsqueeze(1), g2], dim=1).contiguous())   # [F, 2] = Wh^T [g1 g2]
+            grad_attention = torch.cat([ga[:, 0], ga[:, 1]]).unsqueeze(1)
         else:
             P = A.to(torch.float32)
             grad_attention = torch.zeros((2 * weights.shape[1], 1), device=g.device)

@@ -81,3 +81,45 @@ def test_readout_mean_linear_matches_torch(dtype):
     assert torch.allclose(pooled, want_pool, rtol=1e-5, atol=1e-6)
     assert torch.allclose(logits, lin(want_pool), rtol=1e-4, atol=1e-5)
     assert torch.equal(pooled[2], torch.zeros(64, device="cuda"))
+
+
+@pytest.mark.parametrize("F", [7, 16, 64, 256, 300])
+@pytest.mark.parametrize("vdtype", [torch.float16, torch.float32])
+def test_gat_backward_edge_pass_matches_dense_formulas(F, vdtype):
+    """sgx_gat_backward_edges against the reference's dense backward (SG.py:884-1126 restated):
+    softmax_out = g @ Wh^T, dx = S * softmax_out, sg = dx - S * rowsum(dx), mask, LeakyReLU slope."""
+    from sgracex1_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(F)
+    n, alpha = 700, 0.2
+    adj = (torch.rand((n, n), generator=g, device=dev) < 0.02).float() * (torch.rand((n, n), generator=g, device=dev) + 0.1)
+    adj[torch.arange(n), torch.arange(n)] = 1.0
+    adj[torch.rand((n, n), generator=g, device=dev) < 0.002] = -0.5          # stored, masked out
+    adj[3, :] = 0
+    adj[3, torch.randperm(n, generator=g, device=dev)[:600]] = 0.3           # a long row
+    # values a half can hold exactly, so that the fp16 forward sees the same Wh and a as the fp32 formulas
+    Wh = torch.randn((n, F), generator=g, device=dev).half().float()
+    att = (torch.randn((2 * F, 1), generator=g, device=dev) * (0.5 / F ** 0.5)).half().float()
+    G = torch.randn((n, F), generator=g, device=dev)
+    A = ops.Csr.from_dense(adj, vdtype)
+    dense_adj = torch.zeros_like(adj)
+    row = torch.repeat_interleave(torch.arange(n, device=dev), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    dense_adj[row, A.col.long()] = A.val.float()
+    # forward quantities from the kernel itself (checked elsewhere), dense twins from torch
+    _out, E, S = ops.gat_aggregate(A, Wh.to(vdtype), att.reshape(-1).to(vdtype), alpha=alpha, want_edge_outputs=True)
+    e = torch.nn.functional.leaky_relu(Wh @ att[:F] + (Wh @ att[F:]).T, alpha)
+    P = torch.softmax(torch.where(dense_adj > 0, e, torch.full_like(e, -9e15)), dim=1)
+    dx = P * (G @ Wh.T)
+    sg_d = dx - P * dx.sum(1, keepdim=True)
+    sg_d = torch.where(dense_adj > 0, sg_d, torch.zeros_like(sg_d))
+    sg_d = ((e > 0) + alpha * (e <= 0)) * sg_d
+    sg, g1 = ops.gat_backward_edges(A, E, S, G, Wh, alpha)
+    scale = float(sg_d.abs().max())
+    assert torch.allclose(sg, sg_d[row, A.col.long()], rtol=2e-4, atol=2e-5 * scale)
+    assert torch.allclose(g1, sg_d.sum(1), rtol=2e-4, atol=1e-4 * scale)
+    # padded leading dimensions (what the layer's backward passes): same values
+    Whp = torch.zeros((n, (F + 3) // 4 * 4 + 4), device=dev)
+    Whp[:, :F] = Wh
+    sg2, g12 = ops.gat_backward_edges(A, E, S, G, Whp[:, :F], alpha)
+    assert torch.equal(sg2, sg) and torch.equal(g12, g1)

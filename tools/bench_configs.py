@@ -171,10 +171,14 @@ def main():
         att8 = ((torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.3).half()      # 8 vectors of 2 x 32
         t_layer8 = timed(lambda: ops.layer_forward(A, X, Wt, relu=True, gat_attention=att8, gat_heads=8, out=D), 100)
         t_gat8 = timed(lambda: ops.gat_aggregate(A, Wh, att8, relu=True, heads=8), 100)
+        # edge pass of the backward (fp32, as the reference's backward): sampled g . Wh^T + softmax backward
+        _o, E_, S_ = ops.gat_aggregate(A, Wh, att, relu=True, want_edge_outputs=True)
+        Wh32, G32 = Wh.float(), torch.randn((n, P), generator=gen, device=dev)
+        t_bwd = timed(lambda: ops.gat_backward_edges(A, E_, S_, G32, Wh32), 50)
         b_alg = A.nnz * (6 + 8 + P * 2) + (n + 1) * 4 + n * P * 2
         report("c5 ogbn-arxiv shape GAT", A,
                {"ms_layer": t_layer, "ms_gat_aggregate": t_gat, "ms_gcn_aggregate_same_shape": t_gcn,
-                "ms_layer_8_heads": t_layer8, "ms_gat_aggregate_8_heads": t_gat8},
+                "ms_layer_8_heads": t_layer8, "ms_gat_aggregate_8_heads": t_gat8, "ms_gat_backward_edge_pass_fp32": t_bwd},
                {"f_in": 128, "width": P, "heads": "ms_layer: 8 x 32 as one 256-wide single-softmax head (reference semantics, "
                 "nheads only widens W); ms_layer_8_heads: 8 independent softmaxes of 32 columns",
                 "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9})
