@@ -14,7 +14,9 @@
  * Conventions (same as the reference, K.cpp:3762-3774):
  *   - all matrix pointers are DEVICE pointers (HBM), caller-owned; the library only
  *     reads inputs and writes D / E / S / the workspace;
- *   - indices are int32, zero based; CSR = rowPtr[N+1], columnIndex[nnz], values[nnz];
+ *   - indices are int32, zero based; CSR = rowPtr[N+1], columnIndex[nnz], values[nnz]; the number of
+ *     stored entries is read from rowPtr on the device, so columnIndex / values must be valid
+ *     pointers even for a matrix without entries (nothing is read through them then);
  *   - B holds the weights TRANSPOSED, [P_w][M_fea] row-major (K.cpp:3043, MOL cell 16);
  *   - D is [N_adj][P_w] row-major; the feature matrix has M_adj rows (K.cpp:3734);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are

@@ -108,6 +108,12 @@ class Csr:
             raise TypeError("CSR indices must be int32 (the reference's `int` ports, K.cpp:3769-3773)")
         self.n_rows = rowptr.numel() - 1
         self.n_cols = int(n_cols)
+        self._nnz = col.numel()
+        if self._nnz == 0:
+            # an empty tensor has no address; the library wants non-NULL index / value arrays even when
+            # rowPtr says there is nothing to read
+            self.col = torch.zeros(1, dtype=torch.int32, device=self.rowptr.device)
+            self.val = torch.zeros(1, dtype=val.dtype, device=self.rowptr.device)
         self._plan = plan
         self._dead_rows = None
         self._quantized = {}
@@ -120,7 +126,7 @@ class Csr:
             deg = (self.rowptr[1:] - self.rowptr[:-1]).long()
             row = torch.repeat_interleave(torch.arange(self.n_rows, device=self.val.device), deg)
             live = torch.zeros(self.n_rows, dtype=torch.int32, device=self.val.device)
-            live.index_add_(0, row, (self.val > 0).to(torch.int32))
+            live.index_add_(0, row, (self.val[:self.nnz] > 0).to(torch.int32))
             self._dead_rows = bool((live == 0).any().item())
         return self._dead_rows
 
@@ -134,7 +140,7 @@ class Csr:
 
     @property
     def nnz(self):
-        return self.col.numel()
+        return self._nnz
 
     @property
     def plan(self):
@@ -409,9 +415,10 @@ def csr_transpose(A, return_order=False):
     return_order: also the edge permutation (edge k of A^T is edge order[k] of A)."""
     row = torch.repeat_interleave(torch.arange(A.n_rows, device=A.col.device, dtype=torch.int64),
                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
-    key = A.col.to(torch.int64) * A.n_rows + row
+    col, val = A.col[:A.nnz], A.val[:A.nnz]
+    key = col.to(torch.int64) * A.n_rows + row
     order = torch.argsort(key)
-    T = Csr.from_coo(A.col[order].contiguous(), row[order].to(torch.int32).contiguous(), A.val[order].contiguous(),
+    T = Csr.from_coo(col[order].contiguous(), row[order].to(torch.int32).contiguous(), val[order].contiguous(),
                      A.n_cols, A.n_rows)
     return (T, order) if return_order else T
 
