@@ -4,6 +4,10 @@
 
 constexpr int kBlock = 256;              // 4 wavefronts
 constexpr unsigned kOOB = 0xFFFFFFF0u;   // buffer offset that is out of range for any table
+// Row offset that stays out of range after a column offset below 1 MiB is added to it; tables up to
+// kOOBRow bytes with rows under 1 MiB use 32-bit buffer offsets, larger ones 64-bit pointers.
+constexpr unsigned kOOBRow = 0xFFF00000u;
+constexpr unsigned kMaxRowBytes = 0x000FFFF0u;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -24,11 +28,26 @@ template <> struct Elem<float> {
 
 // acc[0:VEC] += a * (VEC elements of type T held in `raw`)
 template <typename T, int VEC> struct Fma;
-template <> struct Fma<f16, 8> {
+// the same in plain C: the compiler turns it into 8 converts + 4 packed fp32 fmas and is free to
+// interleave them with the loads of later edges
+struct FmaPlainF16 {
     static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
         union { u32x4 v; f16 h[8]; } u; u.v = raw;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(a, (float)u.h[i], acc[i]);
+    }
+};
+template <> struct Fma<f16, 8> {
+    // v_fma_mix_f32 reads one half of a packed register as an fp32 operand: acc += a * float(h), one
+    // instruction per element and the same single rounding as convert + fma (the compiler's own choice,
+    // 8 converts + 4 packed fp32 fmas, is 12 instructions per 16 bytes)
+    static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned pair = raw[i];
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * i]) : "v"(pair), "v"(a));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * i + 1]) : "v"(pair), "v"(a));
+        }
     }
 };
 template <> struct Fma<float, 4> {
@@ -39,11 +58,47 @@ template <> struct Fma<float, 4> {
     }
 };
 
-// One gather of VEC elements at byte offset `off` of the table behind `rsrc`.
+// One gather of VEC elements at byte offset `off` of the table behind `rsrc`.  load() and fma() are
+// separate so that a caller can put all loads of a step ahead of the arithmetic in program order.
+template <typename T, int VEC> struct GatherRaw;
+template <> struct GatherRaw<f16, 8> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+    static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) { Fma<f16, 8>::run(acc, a, raw); }
+};
+template <> struct GatherRaw<float, 4> {
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+    static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) { Fma<float, 4>::run(acc, a, raw); }
+};
+template <> struct GatherRaw<f16, 1> {
+    typedef unsigned short raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+    }
+    static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) {
+        union { unsigned short s; f16 h; } u; u.s = raw;
+        acc[0] = __builtin_fmaf(a, (float)u.h, acc[0]);
+    }
+};
+template <> struct GatherRaw<float, 1> {
+    typedef unsigned raw_t;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    }
+    static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) {
+        acc[0] = __builtin_fmaf(a, __builtin_bit_cast(float, raw), acc[0]);
+    }
+};
+
 template <typename T, int VEC> struct Gather;
 template <> struct Gather<f16, 8> {
     static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-        Fma<f16, 8>::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        FmaPlainF16::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
     }
 };
 template <> struct Gather<float, 4> {

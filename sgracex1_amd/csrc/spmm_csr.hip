@@ -26,6 +26,12 @@
 #endif
 #include <stdlib.h>
 
+#ifndef SGX_SPMM_ADJ_STYLE
+#define SGX_SPMM_ADJ_STYLE 0   // A.H: gather + accumulate edge by edge (rolling window of loads)
+#endif
+#ifndef SGX_SPMM_FEA_STYLE
+#define SGX_SPMM_FEA_STYLE 1   // X.W: all gathers of a step, then the arithmetic
+#endif
 #ifndef SGX_SPMM_PIECES
 #define SGX_SPMM_PIECES 1            // pieces of LPR edges per loop iteration (gathers in flight x PIECES)
 #endif
@@ -47,7 +53,7 @@ constexpr double kShortRowDegree = 5.0;      // choose_cpl: mean degree below wh
 //   degree (sgx_plan).  Gathers in flight per lane stay at 8 either way.
 // BIG = the table is 4 GiB or larger: buffer offsets are 32 bit, so the gathers become 64-bit
 // global loads under a per-edge predicate (the all-gathered H of an 8-GPU run crosses this size).
-template <typename T, int VEC, int LPR, int CPL, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG, int STYLE>
 __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int stride, int sub,
                                                  const int32_t *__restrict__ col, const T *__restrict__ val,
                                                  __amdgpu_buffer_rsrc_t rsrc, const T *__restrict__ table,
@@ -57,60 +63,94 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
     // one load each (requested one iteration ahead) and all their gathers are issued before the first
     // is consumed -- SGX_SPMM_PIECES * min(LPR, 8/CPL) * CPL gathers in flight per lane.
     constexpr int PIECES = SGX_SPMM_PIECES;
-    int c_next[PIECES];
+    // What travels from the lane that loaded an edge to the lanes that gather for it: the byte offset
+    // of the neighbour's row (column index x row pitch, multiplied once by the loading lane instead
+    // of once per receiving lane) -- kOOBRow for an edge past the end of the row, which makes every
+    // gather of that slot an out-of-range buffer access (returns 0, no memory traffic) without any
+    // per-gather predicate.  Tables of 4 GiB and more (BIG) keep the column index and a predicate.
+    // (the prefetched column index stays raw until the iteration that uses it: multiplying at fetch time
+    // would put the wait for the load right behind the load)
+    unsigned c_next[PIECES];
     T a_next[PIECES];
-#pragma unroll
-    for (int p = 0; p < PIECES; ++p) {
-        const int idx = e0 + p * stride + sub;
-        c_next[p] = 0;
-        a_next[p] = (T)0;
+    constexpr unsigned kNoEdge = 0xFFFFFFFFu;
+    auto fetch = [&](int idx, unsigned &c, T &a) {
+        c = STYLE == 0 ? 0u : kNoEdge;
+        a = (T)0;
         if (idx < e1) {
-            c_next[p] = __builtin_nontemporal_load(col + idx);  // streamed once: keep L2 for H
-            a_next[p] = __builtin_nontemporal_load(val + idx);
+            c = (unsigned)__builtin_nontemporal_load(col + idx);                 // streamed once: keep L2 for H
+            a = __builtin_nontemporal_load(val + idx);
         }
-    }
+    };
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) fetch(e0 + p * stride + sub, c_next[p], a_next[p]);
     for (int base = e0; base < e1; base += PIECES * stride) {
-        int c[PIECES];
+        unsigned r[PIECES];
         float a[PIECES];
 #pragma unroll
         for (int p = 0; p < PIECES; ++p) {
-            c[p] = c_next[p];
+            r[p] = (BIG || STYLE == 0) ? c_next[p] : (c_next[p] == kNoEdge ? kOOBRow : c_next[p] * ld_bytes);
             a[p] = Elem<T>::to_f32(a_next[p]);
             // the next iteration's (column, value) pairs are requested before this iteration's gathers
-            const int nidx = base + (PIECES + p) * stride + sub;
-            c_next[p] = 0;
-            a_next[p] = (T)0;
-            if (nidx < e1) {
-                c_next[p] = __builtin_nontemporal_load(col + nidx);
-                a_next[p] = __builtin_nontemporal_load(val + nidx);
-            }
+            fetch(base + (PIECES + p) * stride + sub, c_next[p], a_next[p]);
         }
         constexpr int kInFlight = 8 / CPL;                      // edges of one piece whose gathers go together
         constexpr int UNR = LPR < kInFlight ? LPR : kInFlight;
 #pragma unroll 1
         for (int t0 = 0; t0 < LPR; t0 += UNR) {
             if (t0 >= e1 - base) break;
+            if constexpr (!BIG && STYLE == 0) {
+                // gather and accumulate edge by edge; the compiler's schedule keeps a rolling window of
+                // loads in flight across steps (best for the HBM-bound A.H stage)
 #pragma unroll
-            for (int p = 0; p < PIECES; ++p) {
-                const int n = e1 - base - p * stride;            // valid edges in this piece (may be <= 0)
+                for (int p = 0; p < PIECES; ++p) {
+                    const int n = e1 - base - p * stride;            // valid edges in this piece (may be <= 0)
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int t = t0 + u;
-                    const int cc = __shfl(c[p], t, LPR);
-                    const float aa = __shfl(a[p], t, LPR);
+                    for (int u = 0; u < UNR; ++u) {
+                        // here the column index itself travels and every receiving lane forms its offset
+                        // (measured: the A.H stage loses 1 % with the pre-multiplied row offset of STYLE 1)
+                        const int t = t0 + u;
+                        const unsigned cc = (unsigned)__shfl((int)r[p], t, LPR);
+                        const float aa = __shfl(a[p], t, LPR);
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) {
-                        const bool valid = t < n && chunk_off[j] != kOOB;
-                        if constexpr (!BIG) {
+                        for (int j = 0; j < CPL; ++j)
                             Gather<T, VEC>::run(acc + j * VEC, aa, rsrc,
-                                                valid ? (unsigned)cc * ld_bytes + chunk_off[j] : kOOB);
-                        } else {
-                            if (valid)
-                                GatherPtr<T, VEC>::run(acc + j * VEC, aa, reinterpret_cast<const char *>(table) +
-                                                                              (size_t)(unsigned)cc * ld_bytes + chunk_off[j]);
-                        }
+                                                (t < n && chunk_off[j] != kOOB) ? cc * ld_bytes + chunk_off[j] : kOOB);
                     }
                 }
+            } else if constexpr (!BIG) {
+                // all gathers of the step first, then the arithmetic (fewer registers, more wavefronts: best
+                // for X.W, whose table sits in L2 and whose cost is instruction issue)
+                typename GatherRaw<T, VEC>::raw_t raw[PIECES][UNR][CPL];
+                float aa[PIECES][UNR];
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const unsigned rr = (unsigned)__shfl((int)r[p], t0 + u, LPR);
+                        aa[p][u] = __shfl(a[p], t0 + u, LPR);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j)       // a lane whose chunk lies beyond n_feat stays out of range
+                            raw[p][u][j] = GatherRaw<T, VEC>::load(rsrc, chunk_off[j] != kOOB ? rr + chunk_off[j] : kOOB);
+                    }
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) GatherRaw<T, VEC>::fma(acc + j * VEC, aa[p][u], raw[p][u][j]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const unsigned rr = (unsigned)__shfl((int)r[p], t0 + u, LPR);
+                        const float aa = __shfl(a[p], t0 + u, LPR);
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j)
+                            if (rr != 0xFFFFFFFFu && chunk_off[j] != kOOB)
+                                GatherPtr<T, VEC>::run(acc + j * VEC, aa, reinterpret_cast<const char *>(table) +
+                                                                              (size_t)rr * ld_bytes + chunk_off[j]);
+                    }
             }
         }
     }
@@ -151,7 +191,7 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 // wavefront.  Putting both in one grid lets the heavy chunks start first and the short rows fill
 // in around them (on R-MAT the two paths as separate launches took 0.98 + 1.24 ms back to back).
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CPL, bool BIG>
+template <typename T, int VEC, int LPR, int CPL, bool BIG, int STYLE>
 __device__ __forceinline__ void spmm_body(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
@@ -184,7 +224,7 @@ __device__ __forceinline__ void spmm_body(
                 chunk_off[j] = col0 + j * VEC < n_feat ? (unsigned)(col0 + j * VEC) * (unsigned)sizeof(T) : kOOB;
 #pragma unroll
             for (int i = 0; i < LANE_COLS; ++i) acc[i] = 0.0f;
-            accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes,
+            accumulate_edges<T, VEC, LPR, CPL, BIG, STYLE>(acc, e0 + grp * LPR, e1, 64, sub, col, val, rsrc, H, ld_bytes,
                                                     chunk_off);
 #pragma unroll
             for (int off = LPR; off < 64; off <<= 1)
@@ -231,7 +271,7 @@ __device__ __forceinline__ void spmm_body(
                 for (int i = 0; i < LANE_COLS; ++i)
                     if (col0 + i < n_feat) acc[i] = acc_in[r * ld_acc + col0 + i];
             }
-            accumulate_edges<T, VEC, LPR, CPL, BIG>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, chunk_off);
+            accumulate_edges<T, VEC, LPR, CPL, BIG, STYLE>(acc, e0, e1, LPR, sub, col, val, rsrc, H, ld_bytes, chunk_off);
             if (live && acc_out) {
 #pragma unroll
                 for (int i = 0; i < LANE_COLS; ++i)
@@ -263,13 +303,13 @@ __device__ __forceinline__ void spmm_body(
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(SGX_SPMM_PARAMS)
 {
-    spmm_body<T, VEC, LPR, CPL, BIG>(SGX_SPMM_ARGS);
+    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_ADJ_STYLE>(SGX_SPMM_ARGS);
 }
 
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void xw_sparse_kernel(SGX_SPMM_PARAMS)
 {
-    spmm_body<T, VEC, LPR, CPL, BIG>(SGX_SPMM_ARGS);
+    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_FEA_STYLE>(SGX_SPMM_ARGS);
 }
 
 template <typename T>
@@ -422,7 +462,8 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
     const size_t es = sgx_elem_size(dtype);
     const unsigned long long table_bytes = (unsigned long long)n_cols * (unsigned long long)ldh * es;
-    const bool big = table_bytes >= 0xFFFFFFF0ull;                     // beyond 32-bit buffer offsets
+    // 32-bit buffer offsets need the whole table below kOOBRow and a row below 1 MiB (sgx_device.h)
+    const bool big = table_bytes > kOOBRow || (unsigned long long)n_feat * es > kMaxRowBytes;
     if ((unsigned long long)ldh * es >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
     if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
 
