@@ -220,6 +220,8 @@ def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_p
     returned; otherwise D = act(acc_in + A @ H) in H's dtype."""
     _dev2d(H, "H")
     code = dtype_code(H.dtype)
+    if adj.val.dtype != H.dtype:
+        raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
     n_feat = H.shape[1]
     if acc_in is not None:
         _dev(acc_in, "acc_in")
@@ -244,6 +246,9 @@ def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
     _dev2d(X, "X")
     _dev2d(Wt, "Wt")
     code = dtype_code(X.dtype)
+    if Wt.dtype != X.dtype or X.shape[1] != Wt.shape[1]:
+        raise TypeError(f"X [n, M] and Wt [P, M] must share the element type and M (got {X.dtype} {tuple(X.shape)}, "
+                        f"{Wt.dtype} {tuple(Wt.shape)})")
     P, M = Wt.shape
     per16 = 8 if code == SGX_F16 else 4
     ldh = (P + per16 - 1) // per16 * per16 if ldh is None else ldh
