@@ -455,3 +455,33 @@ def test_two_pass_aggregation(sgx, dtype):
     tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-5)
     assert torch.allclose(two.float(), single.float(), **tol)
     assert (two == single).float().mean() > 0.97
+
+
+def test_fp16_subnormals_are_not_flushed(sgx):
+    """Subnormal halves (|x| < 6.1e-5) in W, H and the adjacency values go through both gather loops
+    (X.W with a CSR X uses v_fma_mix_f32, A.H converts and uses packed fmas) like any other value."""
+    dev = torch.device("cuda")
+    n, m, p = 257, 40, 64
+    tiny = torch.tensor(2.0 ** -24, dtype=torch.float16)              # smallest positive half
+    k = torch.arange(1, m * p + 1, dtype=torch.float32).reshape(p, m) % 23 + 1
+    Wt = (k * float(tiny)).half().to(dev)                              # W entries: 1..23 units of 2^-24
+    # X: two ones per row -> H[r] = W[c0] + W[c1] exactly (still subnormal or barely normal)
+    c0 = torch.arange(n) % m
+    c1 = (torch.arange(n) * 7 + 3) % m
+    c1 = torch.where(c1 == c0, (c1 + 1) % m, c1)
+    lo, hi = torch.minimum(c0, c1), torch.maximum(c0, c1)
+    X = sgx.Csr(torch.arange(0, 2 * n + 1, 2, dtype=torch.int32, device=dev),
+                torch.stack([lo, hi], 1).reshape(-1).to(torch.int32).to(dev), torch.ones(2 * n, dtype=torch.float16, device=dev), m)
+    eye = sgx.Csr(torch.arange(n + 1, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
+                  torch.ones(n, dtype=torch.float16, device=dev), n)
+    got = sgx.layer_forward(eye, X, Wt, relu=True)
+    W = Wt.float().cpu().T                                              # [m, p]
+    want = (W[lo] + W[hi]).half()
+    assert (want > 0).all() and (want.float() < 6.2e-5).any()
+    assert torch.equal(got.cpu(), want)
+    # A.H with subnormal adjacency values and a subnormal table
+    A = sgx.Csr(torch.arange(n + 1, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
+                torch.full((n,), 2.0 ** -12, dtype=torch.float16, device=dev), n)
+    H = (torch.arange(1, n * p + 1, dtype=torch.float32).reshape(n, p) % 9 + 1) * 2.0 ** -12
+    out = sgx.spmm(A, H.half().to(dev), relu=False)
+    assert torch.equal(out.cpu(), (H * 2.0 ** -12).half()) and (out > 0).all()
