@@ -247,8 +247,8 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
  * n_heads > 1 (BASELINE config 5; the reference itself has one head, SG.py:1176-1178): the formula
  * above on each slice of n_feat / n_heads columns with its own vector attention[h][0 : 2*F_head],
  * outputs concatenated -- what n_heads single-head calls on the slices give; E/S are [nnz][n_heads].
- * plan (optional): rows it marks long are cut into edge chunks with running softmax states that are
- * merged in a fixed order (single head; with several heads the plan is ignored). */
+ * plan (optional): rows it marks long are cut into edge chunks with per-chunk softmax states that are
+ * merged in a fixed order. */
 size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan);
 int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads,
                       float alpha,

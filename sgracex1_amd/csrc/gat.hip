@@ -252,51 +252,58 @@ __global__ __launch_bounds__(kBlock) void gat_split_kernel(
     }
 }
 
+// (pm, pl are [task][head], row_m / row_l [long row][head]; one head: plain [task] / [long row])
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gat_split_finalize_kernel(
-    int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
-    const float *__restrict__ pacc, int ldp, const float *__restrict__ pm, const float *__restrict__ pl,
-    T *__restrict__ D, int64_t ldd, int relu, const float *__restrict__ fill, float *__restrict__ row_m,
-    float *__restrict__ row_l)
+    int n_long, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ long_row,
+    const int32_t *__restrict__ long_first, const float *__restrict__ pacc, int ldp, const float *__restrict__ pm,
+    const float *__restrict__ pl, T *__restrict__ D, int64_t ldd, int relu, const float *__restrict__ fill,
+    float *__restrict__ row_m, float *__restrict__ row_l)
 {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (int64_t)n_long * n_feat) return;
     const int i = (int)(gid / n_feat), j = (int)(gid % n_feat);
+    const int h = j / f_head;
     const int t0 = long_first[i], t1 = long_first[i + 1];
     float m = -INFINITY;
-    for (int t = t0; t < t1; ++t) m = fmaxf(m, pm[t]);
+    for (int t = t0; t < t1; ++t) m = fmaxf(m, pm[(int64_t)t * n_heads + h]);
     float l = 0.0f, a = 0.0f;
     for (int t = t0; t < t1; ++t) {
-        const float w = rescale_factor(pm[t], m);
-        l += pl[t] * w;
+        const float w = rescale_factor(pm[(int64_t)t * n_heads + h], m);
+        l += pl[(int64_t)t * n_heads + h] * w;
         a += pacc[(int64_t)t * ldp + j] * w;
     }
     float out = l > 0.0f ? a / l : (fill ? fill[j] : 0.0f);
     T v = Elem<T>::from_f32(out);
     D[(int64_t)long_row[i] * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
-    if (j == 0) { row_m[i] = m; row_l[i] = l; }
+    if (j % f_head == 0) { row_m[(int64_t)i * n_heads + h] = m; row_l[(int64_t)i * n_heads + h] = l; }
 }
 
 // softmax values of the long rows' edges, once the rows' (max, sum) are known: workgroup (i, y) walks
 // every gridDim.y-th 256-edge piece of long row i
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gat_split_softmax_kernel(
-    int n_cols, const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const T *__restrict__ val, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
-    const float *__restrict__ row_m, const float *__restrict__ row_l, int filled, float *__restrict__ S)
+    int n_cols, int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ col, const T *__restrict__ val, const float *__restrict__ s1,
+    const float *__restrict__ s2, float alpha, const float *__restrict__ row_m, const float *__restrict__ row_l,
+    int filled, float *__restrict__ S)
 {
     const int i = blockIdx.x;
     const int row = long_row[i];
-    const float m = row_m[i], l = row_l[i], si = s1[row];
     const int e1 = rowptr[row + 1];
     for (int idx = rowptr[row] + blockIdx.y * kBlock + threadIdx.x; idx < e1; idx += gridDim.y * kBlock) {
-        float p = 0.0f;
-        if (l > 0.0f) {
-            if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(leaky(si + s2[col[idx]], alpha) - m) / l;
-        } else if (filled) {
-            p = 1.0f / (float)n_cols;
+        const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+        const int c = col[idx];
+        for (int h = 0; h < n_heads; ++h) {
+            const float m = row_m[(int64_t)i * n_heads + h], l = row_l[(int64_t)i * n_heads + h];
+            float p = 0.0f;
+            if (l > 0.0f) {
+                if (pos) p = expf(leaky(s1[(int64_t)row * n_heads + h] + s2[(int64_t)c * n_heads + h], alpha) - m) / l;
+            } else if (filled) {
+                p = 1.0f / (float)n_cols;
+            }
+            S[(int64_t)idx * n_heads + h] = p;
         }
-        S[idx] = p;
     }
 }
 
@@ -331,24 +338,35 @@ __global__ __launch_bounds__(kBlock) void gat_scores_heads_kernel(int n_cols, in
     s2[gid] = p2;
 }
 
-template <typename T, int VEC, int LPR>
+// TASKS = false: work item = a row (rows over long_threshold edges are left to the tasks).
+// TASKS = true:  work item = a task of the plan (an edge chunk of a long row): the lane group leaves the
+//                chunk's state -- per head (max, sum) in pm / pl, the unnormalised weighted row in pacc --
+//                for gat_split_finalize_kernel; n_rows is then the number of tasks.
+template <typename T, int VEC, int LPR, bool TASKS>
 __global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
     int n_rows, int n_cols, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ col, const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes,
     unsigned ld_bytes, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
     T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
-    const float *__restrict__ fill, int share)
+    const float *__restrict__ fill, int share, int long_threshold, const int32_t *__restrict__ task_row,
+    const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1, float *__restrict__ pacc, int ldp,
+    float *__restrict__ pm, float *__restrict__ pl)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR, grp = lane / LPR;
-    const int64_t r = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;
+    const int64_t w = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW + grp;      // work item
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
-    const bool live = r < n_rows;
+    bool live = w < n_rows;
     int e0 = 0, e1 = 0;
-    if (live) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    int64_t r = w;
+    if (live) {
+        if (TASKS) { r = task_row[w]; e0 = task_e0[w]; e1 = task_e1[w]; }
+        else { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    }
+    if (!TASKS && live && long_threshold > 0 && e1 - e0 > long_threshold) { live = false; e1 = e0; }
     const float uniform = 1.0f / (float)n_cols;
 
     for (int c0 = 0; c0 < n_feat; c0 += TILE) {
@@ -378,8 +396,8 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
             const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
             softmax_merge(m, l, m2, l2);
         }
-        const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
-        const bool dead = live && mine && !(l > 0.0f) && fill != nullptr;
+        const float inv_l = TASKS ? 1.0f : (l > 0.0f ? 1.0f / l : 0.0f);      // a task stays unnormalised
+        const bool dead = !TASKS && live && mine && !(l > 0.0f) && fill != nullptr;
 
         // pass 2: weighted gather
         float acc[VEC];
@@ -401,10 +419,19 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
                 if (writer) {
                     const int64_t o = (int64_t)(base + t) * n_heads + h;
                     if (E) E[o] = x;
-                    if (S) S[o] = dead ? uniform : p;
+                    if (!TASKS && S) S[o] = dead ? uniform : p;
                 }
                 Gather<T, VEC>::run(acc, p, rsrc, mine ? (unsigned)cc * ld_bytes + col_off : kOOB);
             }
+        }
+        if (TASKS) {
+            if (live && mine) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (col0 + i < n_feat) pacc[w * ldp + col0 + i] = acc[i];
+                if (writer) { pm[w * n_heads + h] = m; pl[w * n_heads + h] = l; }
+            }
+            continue;
         }
         if (live && mine) {
             T out[VEC];
@@ -466,7 +493,7 @@ struct GatArgs {
     void *D;
     float *E, *S, *s;
     const float *fill;
-    const sgx_plan *plan;      // long rows -> split path (single head only)
+    const sgx_plan *plan;      // long rows -> split path
     float *split;              // scratch of the split path, behind the scores / column means
     int vec_ok, vec_store;
     hipStream_t stream;
@@ -490,11 +517,40 @@ int gat_launch_one(const GatArgs &a)
         hipLaunchKernelGGL((gat_scores_heads_kernel<T>), dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                            a.stream, a.n_cols, a.n_heads, f_head, (const T *)a.Wh, a.ldh, (const T *)a.att, h1, h2);
         SGX_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows,
+        const sgx_plan *hp = a.plan;
+        const int thr = (hp && hp->n_long > 0) ? hp->long_threshold : 0;
+        const int ldp = (int)sgx_align_up((size_t)a.n_feat, 4);
+        float *pacc = a.split, *pm = nullptr, *pl = nullptr, *row_m = nullptr, *row_l = nullptr;
+        if (thr > 0) {
+            pm = pacc + (size_t)hp->n_tasks * ldp;
+            pl = pm + (size_t)hp->n_tasks * a.n_heads;
+            row_m = pl + (size_t)hp->n_tasks * a.n_heads;
+            row_l = row_m + (size_t)hp->n_long * a.n_heads;
+        }
+        hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, false>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows,
                            a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
                            a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill,
-                           share);
+                           share, thr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
         SGX_LAUNCH_CHECK();
+        if (thr > 0) {
+            const unsigned tgrid = (unsigned)((hp->n_tasks + rows_per_block - 1) / rows_per_block);
+            hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, true>), dim3(tgrid), dim3(kBlock), 0, a.stream,
+                               hp->n_tasks, a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val,
+                               (const T *)a.Wh, a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, nullptr,
+                               a.vec_store, nullptr, share, 0, hp->task_row, hp->task_e0, hp->task_e1, pacc, ldp, pm, pl);
+            SGX_LAUNCH_CHECK();
+            const int64_t total = (int64_t)hp->n_long * a.n_feat;
+            hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock),
+                               0, a.stream, hp->n_long, a.n_feat, a.n_heads, f_head, hp->long_row, hp->long_first, pacc, ldp,
+                               pm, pl, (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l);
+            SGX_LAUNCH_CHECK();
+            if (a.S) {
+                hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(hp->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols,
+                                   a.n_heads, hp->long_row, a.rowptr, a.col, (const T *)a.val, h1, h2, a.alpha, row_m, row_l,
+                                   a.fill != nullptr, a.S);
+                SGX_LAUNCH_CHECK();
+            }
+        }
         return SGX_OK;
     }
     float *s1 = a.s, *s2 = a.s + a.n_cols;                    // scores of every row of the table
@@ -513,11 +569,11 @@ int gat_launch_one(const GatArgs &a)
         SGX_LAUNCH_CHECK();
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, pacc, ldp, pm, pl, (T *)a.D, a.ldd,
-                           a.relu, a.fill, row_m, row_l);
+                           a.stream, p->n_long, a.n_feat, 1, a.n_feat, p->long_row, p->long_first, pacc, ldp, pm, pl, (T *)a.D,
+                           a.ldd, a.relu, a.fill, row_m, row_l);
         SGX_LAUNCH_CHECK();
         if (a.S) {
-            hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols,
+            hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols, 1,
                                p->long_row, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, row_m, row_l,
                                a.fill != nullptr, a.S);
             SGX_LAUNCH_CHECK();
@@ -553,7 +609,7 @@ size_t base_scratch_floats(int n_cols, int n_feat, int n_heads, int fill_dead_ro
     if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
     return sgx_align_up(floats, 64);
 }
-bool uses_split(const sgx_plan *plan, int n_heads) { return plan && plan->n_long > 0 && n_heads == 1; }
+bool uses_split(const sgx_plan *plan) { return plan && plan->n_long > 0; }
 }  // namespace
 
 extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan)
@@ -561,8 +617,9 @@ extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int
     if (n_cols < 0 || n_feat < 1) return 0;
     if (n_heads < 1) n_heads = 1;
     size_t floats = base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
-    if (uses_split(plan, n_heads))        // per task: fp32 partial row + (max, sum); per long row: (max, sum)
-        floats += (size_t)plan->n_tasks * (sgx_align_up((size_t)n_feat, 4) + 2) + (size_t)2 * plan->n_long;
+    if (uses_split(plan))        // per task: fp32 partial row + (max, sum) per head; per long row: (max, sum) per head
+        floats += (size_t)plan->n_tasks * (sgx_align_up((size_t)n_feat, 4) + 2 * (size_t)n_heads) +
+                  (size_t)2 * plan->n_long * n_heads;
     return sgx_align_up(floats * sizeof(float), 256);
 }
 
@@ -590,7 +647,7 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
     a.fill = nullptr;
-    a.plan = uses_split(plan, n_heads) ? plan : nullptr;
+    a.plan = uses_split(plan) ? plan : nullptr;
     a.split = s_scratch + base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
     if (fill_dead_rows) {
         float *partial = s_scratch + (size_t)2 * n_cols * n_heads, *mean = partial + (size_t)kMeanSlabs * n_feat;

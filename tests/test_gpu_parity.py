@@ -349,6 +349,51 @@ def test_gat_long_rows_take_the_split_path(sgx, oracle, dtype, F):
     np.testing.assert_allclose(filled[1500].float().cpu().numpy(), Wh.mean(0), **tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("heads,f_head", [(8, 32), (4, 16), (3, 5)])
+def test_gat_multi_head_long_rows(sgx, oracle, dtype, heads, f_head):
+    """Several heads on a graph with hub rows: the plan's tasks leave per-head chunk states that are
+    merged in task order -- against the oracle per column slice, and against the unsplit kernel."""
+    rng = np.random.default_rng(heads + f_head)
+    n, F = 2500, heads * f_head
+    rp, ci, va = _rand_csr(rng, n, n, 5.0, empty_frac=0.0)
+    dense = _dense(rp, ci, np.abs(va) + 0.1, n, n)
+    dense[np.arange(n), np.arange(n)] = 1.0
+    for r, k, sign in ((9, 2000, 1.0), (1200, 700, 1.0), (2400, 300, -1.0)):
+        cols = rng.choice(n, k, replace=False)
+        dense[r, :] = 0
+        dense[r, cols] = sign * (rng.random(k) + 0.05)
+    dense[9, rng.choice(n, 200, replace=False)] *= -1
+    rows, cols = np.nonzero(dense)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    va = dense[rows, cols].astype(np.float32)
+    Wh = rng.standard_normal((n, F)).astype(np.float32)
+    att = (rng.standard_normal((heads, 2 * f_head)) * (0.6 / np.sqrt(f_head))).astype(np.float32)
+    if dtype == torch.float16:
+        va, Wh, att = _h(oracle, va), _h(oracle, Wh), _h(oracle, att)
+    csr = (rp, cols.astype(np.int32), va)
+    A = _csr(sgx, csr, n, dtype)
+    assert A.plan.long_rows == 3
+    got, gE, gS = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, want_edge_outputs=True,
+                                    heads=heads, fill_dead_rows=False)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=3e-5, atol=3e-6)
+    for h in range(heads):
+        sl = slice(h * f_head, (h + 1) * f_head)
+        D, E, S = oracle.gat_f64(1, csr, np.ascontiguousarray(Wh[:, sl]), att[h], 0.2)
+        np.testing.assert_allclose(got[:, sl].float().cpu().numpy(), D, **tol)
+        np.testing.assert_allclose(gE[:, h].cpu().numpy(), E, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gS[:, h].cpu().numpy(), S, rtol=2e-4, atol=1e-7)
+    assert (got[2400] == 0).all()
+    plain = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads, fill_dead_rows=False,
+                              use_plan=False)
+    np.testing.assert_allclose(got.float().cpu().numpy(), plain.float().cpu().numpy(), rtol=tol["rtol"], atol=max(tol["atol"], 1e-5))
+    again = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads, fill_dead_rows=False)
+    assert torch.equal(again, got)
+    filled = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=0, heads=heads)
+    np.testing.assert_allclose(filled[2400].float().cpu().numpy(), Wh.mean(0), **tol)
+
+
 def test_gat_layer_through_desc(sgx, oracle):
     d = load("cora")
     rng = np.random.default_rng(3)
