@@ -136,3 +136,18 @@ def test_graft_entry_build_check_passes():
     declared = int(re.search(r"#define\s+SGX_VERSION\s+(\d+)", open(HEADER).read()).group(1))
     assert _lib.lib.sgx_version() == declared
     assert callable(entry.build) and callable(entry.smoke)
+
+
+def test_package_fails_loudly_without_the_library(tmp_path):
+    """No HIP library -> importing the accelerated path raises; there is no CPU or torch fallback."""
+    import sys
+    env = dict(os.environ, SGX_LIB_PATH=str(tmp_path / "no_such_libsgx.so"))
+    out = subprocess.run([sys.executable, "-c", "import sgracex1_amd.ops"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode != 0
+    assert "ImportError" in out.stderr and "no other backend" in out.stderr
+    # a file that is not a loadable library fails too (OSError from the loader), it is not skipped
+    bogus = tmp_path / "libsgx.so"
+    bogus.write_bytes(b"not an ELF file")
+    out = subprocess.run([sys.executable, "-c", "import sgracex1_amd.ops"], cwd=ROOT, env=dict(env, SGX_LIB_PATH=str(bogus)),
+                         capture_output=True, text=True)
+    assert out.returncode != 0 and "Error" in out.stderr
