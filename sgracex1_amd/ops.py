@@ -91,10 +91,10 @@ class Plan:
     def reordered(self):
         return bool(lib.sgx_plan_reordered(self._h))
 
-    def __del__(self):
+    def __del__(self, _destroy=lib.sgx_plan_destroy):        # bound at definition: module globals are gone at shutdown
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib.sgx_plan_destroy(h)
+            _destroy(h)
 
 
 class Csr:
