@@ -5,9 +5,10 @@
 //     alpha_ij = softmax_j(e_ij)                     (rows of the masked dense matrix)
 //     D_i = act( sum_j alpha_ij Wh_j )
 // The emulation builds dense N x N matrices; here the softmax runs over the CSR row: one group
-// of LPR lanes per row (the same sblock layout as spmm_csr.hip), pass 1 = online max / sum over
-// the 4-byte scores, pass 2 = the 16-byte row gathers weighted by alpha_ij.  The hardware's
-// per-edge side outputs E (pre-softmax) and S (softmax) (SG.py:500-502) are optional.
+// of LPR lanes per row (the same sblock layout as spmm_csr.hip) walks the edges once with a running
+// (max, sum, weighted row) state, rescaled when the maximum moves; the row is normalised at the end.
+// The hardware's per-edge side outputs E (pre-softmax) and S (softmax) (SG.py:500-502) are optional
+// (S costs a second, gather-free walk over the row once its max and sum are known).
 // Rows with no positive edge: the emulation's masked dense row is constant (-9e15 everywhere,
 // SG.py:638-641), its softmax uniform over all N nodes, so the row receives the mean of all rows
 // of Wh.  sym_norm2's self loops (SG.py:42) keep the plain path away from this case, the quantised
@@ -67,6 +68,11 @@ __device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, floa
     m = mn;
 }
 
+__device__ __forceinline__ float rescale_factor(float m_old, float m_new)
+{
+    return m_old == -INFINITY ? 0.0f : expf(m_old - m_new);        // (-inf) - (-inf) never reaches expf
+}
+
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     int n_rows, int n_cols, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -89,43 +95,40 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     if (live) { e0 = rowptr[r]; e1 = rowptr[r + 1]; si = s1[r]; }
     if (live && long_threshold > 0 && e1 - e0 > long_threshold) { live = false; e1 = e0; }   // the split path owns it
 
-    // pass 1: running max and sum of exp over the row's positive edges
-    float m = -INFINITY, l = 0.0f;
-    for (int idx = e0 + sub; idx < e1; idx += LPR) {
-        if (Elem<T>::to_f32(val[idx]) > 0.0f) {
-            const float x = leaky(si + s2[col[idx]], alpha);
-            softmax_merge(m, l, x, 1.0f);
-        }
-    }
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) {
-        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
-        softmax_merge(m, l, m2, l2);
-    }
-    const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
-    const bool dead = live && !(l > 0.0f) && fill != nullptr;
     const float uniform = 1.0f / (float)n_cols;
 
-    // pass 2: weighted gather of the neighbour rows
+    // One pass over the row's edges with a running softmax state (max m, sum l, weighted row acc): a piece
+    // of LPR edges is scored by its lanes (one edge each), the piece maximum is reduced over the group, the
+    // state is rescaled when the maximum moves, then the piece's rows are gathered with weights exp(x - m).
+    // Rows of up to LPR edges -- most rows of a citation graph at F = 256 -- never rescale.
     for (int c0 = 0; c0 < n_feat; c0 += TILE) {
         const int col0 = c0 + sub * VEC;
         const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        float m = -INFINITY, l = 0.0f;              // l: this lane's share of the sum
         float acc[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
         for (int base = e0; base < e1; base += LPR) {
             const int idx = base + sub;
             int c = 0;
-            float p = 0.0f;
+            float x = -INFINITY;
             if (idx < e1) {
                 c = col[idx];
-                const float x = leaky(si + s2[c], alpha);
-                if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(x - m) * inv_l;
-                if (c0 == 0) {
-                    if (E) E[idx] = x;
-                    if (S) S[idx] = dead ? uniform : p;
-                }
+                const float xe = leaky(si + s2[c], alpha);
+                if (E && c0 == 0) E[idx] = xe;
+                if (Elem<T>::to_f32(val[idx]) > 0.0f) x = xe;
             }
+            float pmax = x;
+#pragma unroll
+            for (int off = 1; off < LPR; off <<= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off));
+            if (pmax == -INFINITY) continue;        // no live edge in this piece (uniform across the group)
+            const float m_new = fmaxf(m, pmax);
+            const float scale = rescale_factor(m, m_new);
+            const float p = x == -INFINITY ? 0.0f : expf(x - m_new);
+            m = m_new;
+            l = l * scale + p;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] *= scale;
             const int n = e1 - base;
 #pragma unroll 1
             for (int t0 = 0; t0 < LPR; t0 += UNR) {
@@ -140,12 +143,22 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
                 }
             }
         }
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) l += __shfl_xor(l, off);
+        const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+        const bool dead = live && !(l > 0.0f) && fill != nullptr;
+        if (S && c0 == 0) {                         // the softmax values, now that the row's (m, l) are known
+            for (int idx = e0 + sub; idx < e1; idx += LPR) {
+                float p = 0.0f;
+                if (dead) p = uniform;
+                else if (Elem<T>::to_f32(val[idx]) > 0.0f) p = expf(leaky(si + s2[col[idx]], alpha) - m) * inv_l;
+                S[idx] = p;
+            }
+        }
         if (live && col0 < n_feat) {
             T out[VEC];
-            if (dead) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc[i] = (col0 + i < n_feat) ? fill[col0 + i] : 0.0f;
-            }
+            for (int i = 0; i < VEC; ++i) acc[i] = dead ? ((col0 + i < n_feat) ? fill[col0 + i] : 0.0f) : acc[i] * inv_l;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 T v = Elem<T>::from_f32(acc[i]);
@@ -171,11 +184,6 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
 // (m = max m_t, l = sum l_t e^(m_t - m), row = sum acc_t e^(m_t - m) / l): the same softmax, and
 // the same bits from run to run.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float rescale_factor(float m_old, float m_new)
-{
-    return m_old == -INFINITY ? 0.0f : expf(m_old - m_new);        // (-inf) - (-inf) never reaches expf
-}
-
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_split_kernel(
     int n_tasks, int n_feat, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
@@ -223,11 +231,18 @@ __global__ __launch_bounds__(kBlock) void gat_split_kernel(
             l = l * scale + p;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] *= scale;
-            const int n = te1 - base < LPR ? te1 - base : LPR;
-            for (int t = 0; t < n; ++t) {
-                const int cc = __shfl(c, t, LPR);
-                const float pp = __shfl(p, t, LPR);
-                Gather<T, VEC>::run(acc, pp, rsrc, col_off != kOOB ? (unsigned)cc * ld_bytes + col_off : kOOB);
+            const int n = te1 - base;
+            constexpr int UNR = LPR < 8 ? LPR : 8;
+#pragma unroll 1
+            for (int t0 = 0; t0 < LPR; t0 += UNR) {
+                if (t0 >= n) break;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int t = t0 + u;
+                    const int cc = __shfl(c, t, LPR);
+                    const float pp = __shfl(p, t, LPR);
+                    Gather<T, VEC>::run(acc, pp, rsrc, (t < n && col_off != kOOB) ? (unsigned)cc * ld_bytes + col_off : kOOB);
+                }
             }
         }
 #pragma unroll
