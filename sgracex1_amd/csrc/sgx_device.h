@@ -58,20 +58,23 @@ template <> struct Fma<float, 4> {
     }
 };
 
+#ifndef SGX_GATHER_AUX
+#define SGX_GATHER_AUX 0     // cache-policy bits of the 16-byte gathers (experiment knob: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 // One gather of VEC elements at byte offset `off` of the table behind `rsrc`.  load() and fma() are
 // separate so that a caller can put all loads of a step ahead of the arithmetic in program order.
 template <typename T, int VEC> struct GatherRaw;
 template <> struct GatherRaw<f16, 8> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SGX_GATHER_AUX);
     }
     static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) { Fma<f16, 8>::run(acc, a, raw); }
 };
 template <> struct GatherRaw<float, 4> {
     typedef u32x4 raw_t;
     static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SGX_GATHER_AUX);
     }
     static __device__ __forceinline__ void fma(float *acc, float a, raw_t raw) { Fma<float, 4>::run(acc, a, raw); }
 };
@@ -98,12 +101,12 @@ template <> struct GatherRaw<float, 1> {
 template <typename T, int VEC> struct Gather;
 template <> struct Gather<f16, 8> {
     static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-        FmaPlainF16::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        FmaPlainF16::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SGX_GATHER_AUX));
     }
 };
 template <> struct Gather<float, 4> {
     static __device__ __forceinline__ void run(float *acc, float a, __amdgpu_buffer_rsrc_t rsrc, unsigned off) {
-        Fma<float, 4>::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        Fma<float, 4>::run(acc, a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, SGX_GATHER_AUX));
     }
 };
 template <> struct Gather<f16, 1> {
