@@ -197,12 +197,20 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     if (stream >= n_streams) return;                            // leftover wavefronts of the last workgroup
     const int n_base = cg * NTW * 16;
 
+    // Which output column MFMA row i of column tile nt stands for.  With an even number of tiles the two
+    // tiles of a pair interleave in groups of 4 -- tile 2q takes columns 8g..8g+3 and tile 2q+1 columns
+    // 8g+4..8g+7 of the pair's 32 -- so that the 4 + 4 results a lane ends up with are 8 consecutive
+    // columns of one row of H: one 16-byte store instead of two 8-byte ones.
+    constexpr bool PAIRED = (NTW % 2 == 0);
+    auto column_of = [&](int nt, int i) {
+        return PAIRED ? n_base + (nt / 2) * 32 + 8 * (i / 4) + 4 * (nt % 2) + (i % 4) : n_base + nt * 16 + i;
+    };
     f16x8 a[KS][NTW];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int n = n_base + nt * 16 + l15;
+            const int n = column_of(nt, l15);
             a[ks][nt] = load_k8(Wt + (int64_t)n * ldw, ks * 32 + 8 * lq, M, n < P, true);
         }
 
@@ -249,19 +257,37 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = tile * (MT * 16) + mt * 16 + l15;
             if (m >= n_rows) continue;
+            if constexpr (PAIRED) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int n = n_base + nt * 16 + 4 * lq;
-                f16x4 o;
+                for (int q = 0; q < NTW / 2; ++q) {
+                    const int n = n_base + q * 32 + 8 * lq;          // column_of(2q, 4 lq) .. column_of(2q+1, 4 lq + 3)
+                    f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
-                f16 *dst = H + m * ldh + n;
-                if (h_aligned && n + 4 <= ldh) {
-                    *reinterpret_cast<f16x4 *>(dst) = o;
-                } else {
+                    for (int j = 0; j < 4; ++j) { o[j] = (f16)acc[mt][2 * q][j]; o[4 + j] = (f16)acc[mt][2 * q + 1][j]; }
+                    f16 *dst = H + m * ldh + n;
+                    if (h_aligned && n + 8 <= ldh && (ldh % 8 == 0) && ((uintptr_t)H % 16 == 0)) {
+                        *reinterpret_cast<f16x8 *>(dst) = o;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < ldh) dst[j] = o[j];
+                        for (int j = 0; j < 8; ++j)
+                            if (n + j < ldh) dst[j] = o[j];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int n = n_base + nt * 16 + 4 * lq;
+                    f16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
+                    f16 *dst = H + m * ldh + n;
+                    if (h_aligned && n + 4 <= ldh) {
+                        *reinterpret_cast<f16x4 *>(dst) = o;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (n + j < ldh) dst[j] = o[j];
+                    }
                 }
             }
         }
