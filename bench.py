@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="s100m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", action="store_true",
+                    help="N = 1: run both layers in SGX_ACC_REF_HALF with SPMM_BLOCK 4 -- the reference's half arithmetic, "
+                         "bit for bit (the setting that reproduces its csim log)")
     ap.add_argument("--cpu-sample-frac", type=float, default=0.25)
     ap.add_argument("--cut", type=float, default=0.1,
                     help="N > 1: share of a partition's edges whose column is drawn from the whole graph "
@@ -201,12 +204,13 @@ def main():
     n_ev = 2 * args.steps
     ev = [(Event(), Event()) for _ in range(n_ev)]
 
+    mode = dict(acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=4) if args.exact else {}
     if world == 1:
         def step(i, timed):
             e1 = (ev[2 * i][0].handle, ev[2 * i][1].handle) if timed else None
             e2 = (ev[2 * i + 1][0].handle, ev[2 * i + 1][1].handle) if timed else None
-            ops.layer_forward(A, X, W1t, relu=True, out=D1, agg_events=e1)
-            ops.layer_forward(A, D1, W2t, relu=False, out=D2, agg_events=e2)
+            ops.layer_forward(A, X, W1t, relu=True, out=D1, agg_events=e1, **mode)
+            ops.layer_forward(A, D1, W2t, relu=False, out=D2, agg_events=e2, **mode)
     else:
         backend = sdist.hip_backend()
         bounds = [g * n for g in range(world + 1)]
@@ -319,7 +323,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (f32 accumulate)", "data": "synthetic",
+        "dtype": "f16 (every product and add rounded to f16, 4 partial sums: the reference's arithmetic)" if args.exact
+                 else "f16 (f32 accumulate)", "data": "synthetic",
         "config": {"workload": args.workload, "nodes_per_gpu": n, "edges_per_gpu": nnz, "generator": wl["gen"],
                    "f_in": wl["f_in"], "hidden": hidden,
                    "layer1": "gemm_mode=0 sparse X, relu=1" if wl["x_density"] else "gemm_mode=1 dense X, relu=1",

@@ -55,7 +55,7 @@ static inline int64_t sgx_ldh(int dtype, int P) {
 }
 
 // SGX_ACC_REF_HALF stages (refhalf.hip), fp16 only
-int sgx_refhalf_csr(int spmm_block, int threads, int relu, int n_rows, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
+int sgx_refhalf_csr(int spmm_block, int threads, int relu, int n_rows, int n_cols, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
                     const void *values, const void *table, int64_t ldt, void *out, int64_t ldo, hipStream_t s);
 int sgx_refhalf_dense(int spmm_block, int threads, int n_rows, int M, int n_feat, const void *X, int64_t ldx, const void *Wt,
                       int64_t ldw, void *out, int64_t ldo, hipStream_t s);

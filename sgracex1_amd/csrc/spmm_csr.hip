@@ -461,7 +461,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     if (acc_mode == SGX_ACC_REF_HALF) {
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
         if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
-        return sgx_refhalf_csr(spmm_block, ref_threads, relu, n_rows, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, stream);
+        return sgx_refhalf_csr(spmm_block, ref_threads, relu, n_rows, n_cols, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, stream);
     }
     if (acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;

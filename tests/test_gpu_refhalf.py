@@ -105,3 +105,24 @@ def test_layer_bit_exact_with_thread_splits(oracle, name, fea_threads, adj_threa
     want2 = oracle.layer_refhalf(1, 0, d["adj"], h, w2t, **kw)
     got2 = ops.layer_forward(A, _dev(h), _dev(w2t), relu=0, acc_mode=ops.SGX_ACC_REF_HALF, **kw)
     assert np.array_equal(got2.cpu().numpy().view(np.uint16), want2.view(np.uint16))
+
+
+@pytest.mark.parametrize("M,P", [(300, 64), (130, 24), (64, 256), (9, 40), (129, 8), (1433, 16)])
+@pytest.mark.parametrize("spmm_block,fea_threads", [(1, 1), (4, 1), (3, 2)])
+def test_dense_stage_bit_exact_random(oracle, M, P, spmm_block, fea_threads):
+    """Dense X (every position of a row takes part, zeros included) through the lane-group kernel: several
+    blocks of k, widths from one lane to 32 lanes per row, odd M -- against the oracle's model."""
+    from sgracex1_amd import ops
+    rng = np.random.default_rng(M * 7 + P)
+    n = 1100
+    x = (rng.standard_normal((n, M)) * (rng.random((n, M)) < 0.7)).astype(np.float16)
+    wt = (rng.standard_normal((P, M)) * (1.0 / np.sqrt(M))).astype(np.float16)
+    eye = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n, np.float32))
+    want, H = oracle.layer_refhalf(1, 0, eye, x, wt, spmm_block=spmm_block, fea_threads=fea_threads, return_h=True)
+    got = ops.xw_dense(_dev(x), _dev(wt), acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block)
+    if fea_threads == 1:
+        assert np.array_equal(got.cpu().numpy().view(np.uint16), H.view(np.uint16))
+    A = _csr(ops, eye, n)
+    full = ops.layer_forward(A, _dev(x), _dev(wt), relu=0, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block,
+                             fea_threads=fea_threads)
+    assert np.array_equal(full.cpu().numpy().view(np.uint16), want.view(np.uint16))
