@@ -135,3 +135,28 @@ def test_full_size_two_layer_forward_on_sampled_rows(workload, oracle):
     want_d2 = oracle.spmm_f32(0, (arp, acol, aval), H2[auniq].float().cpu().numpy())
     np.testing.assert_allclose(D2[rows].float().cpu().numpy(), want_d2, rtol=2e-3, atol=3e-4)
     assert torch.isfinite(D2.float()).all() and float(D2.float().abs().max()) > 0
+
+
+def test_full_size_exact_mode_bits(workload, oracle):
+    """SGX_ACC_REF_HALF at the bench's full size: sampled sblocks (4 consecutive rows starting at a multiple
+    of 4, SPMM_BLOCK = 4) recomputed by the oracle's model of the reference's half arithmetic -- same bits."""
+    from sgracex1_amd import ops
+    A, _X, _W1t, _W2t = workload
+    n, P = A.n_rows, 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+    H = (torch.rand((n, P), generator=g, device=dev) - 0.3).half()
+    D = ops.spmm(A, H, relu=True, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=4)
+    starts = (torch.randint(0, n // 4, (400,), generator=g, device=dev).unique() * 4)
+    rows = (starts[:, None] + torch.arange(4, device=dev)[None, :]).reshape(-1)
+    srp, scol, sval, uniq = _sample_rows(A, rows)
+    table = H[uniq].cpu().numpy()                                  # float16 [n_uniq, P]
+    eye = np.eye(P, dtype=np.float16)
+    want = oracle.layer_refhalf(1, 1, (srp, scol, sval.astype(np.float16)), table, eye, N=rows.numel(), M_adj=table.shape[0],
+                                spmm_block=4)
+    got = D[rows].cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    # and it is a different, observable arithmetic: not the fp32-accumulate result everywhere
+    plain = ops.spmm(A, H, relu=True)[rows].cpu().numpy()
+    assert (plain.view(np.uint16) != got.view(np.uint16)).mean() > 0.05
+    assert np.abs(plain.astype(np.float32) - got.astype(np.float32)).max() < 4e-3
