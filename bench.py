@@ -204,6 +204,8 @@ def main():
     n_ev = 2 * args.steps
     ev = [(Event(), Event()) for _ in range(n_ev)]
 
+    if args.exact and world > 1:
+        sys.exit("--exact is a one-GPU measurement (the reference's sequential half arithmetic has no partitioned form here)")
     mode = dict(acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=4) if args.exact else {}
     if world == 1:
         def step(i, timed):
