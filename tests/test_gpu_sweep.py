@@ -71,3 +71,34 @@ def test_layer_forward_random_case(oracle, dtype, seed):
     if not c["gat"]:
         empty = np.diff(a_csr[0]) == 0
         assert not got[torch.as_tensor(empty, device=dev)].any()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_exact_mode_random_case(oracle, seed):
+    """SGX_ACC_REF_HALF over random shapes, densities, SPMM_BLOCK and thread splits, both feature modes:
+    the layer's bits against the oracle's model of the reference's half arithmetic."""
+    from sgracex1_amd import ops
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.choice([5, 64, 333, 1000, 1500, 2100]))
+    M_fea = int(rng.choice([1, 3, 8, 31, 64, 130, 257]))
+    P = int(rng.choice([1, 7, 8, 16, 24, 25, 32, 41, 64, 100, 128, 200, 256]))
+    spmm_block = int(rng.choice([1, 2, 3, 4, 8]))
+    fea_threads, adj_threads = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4]))
+    gemm_mode, relu = int(rng.random() < 0.5), int(rng.random() < 0.5)
+    adj = ((rng.random((N, N)) < float(rng.choice([0.005, 0.03, 0.3]))) * (rng.random((N, N)) - 0.3)).astype(np.float16)
+    x = ((rng.random((N, M_fea)) < float(rng.choice([0.05, 0.5, 1.0]))) * rng.standard_normal((N, M_fea))).astype(np.float16)
+    Wt = (rng.standard_normal((P, M_fea)) * (0.7 / np.sqrt(M_fea))).astype(np.float16)
+    a_csr, x_csr = _csr_from_dense(adj.astype(np.float32)), _csr_from_dense(x.astype(np.float32))
+    fea = x_csr if gemm_mode == 0 else x
+    kw = dict(spmm_block=spmm_block, fea_threads=fea_threads, adj_threads=adj_threads)
+    want = oracle.layer_refhalf(gemm_mode, relu, a_csr, fea, Wt, N=N, M_adj=N, **kw)
+    dev = torch.device("cuda")
+
+    def up(csr, n_cols):
+        return ops.Csr(torch.as_tensor(csr[0], device=dev), torch.as_tensor(csr[1], device=dev),
+                       torch.as_tensor(csr[2], device=dev).half(), n_cols)
+
+    X = up(x_csr, M_fea) if gemm_mode == 0 else torch.as_tensor(x, device=dev)
+    got = ops.layer_forward(up(a_csr, N), X, torch.as_tensor(Wt, device=dev), relu=relu, acc_mode=ops.SGX_ACC_REF_HALF, **kw)
+    case = dict(N=N, M_fea=M_fea, P=P, gemm_mode=gemm_mode, relu=relu, **kw)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16)), case
