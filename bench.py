@@ -13,8 +13,9 @@ sparse input features (F_in = 1433, density 1.27 %).  Output: ONE JSON line on r
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a
 partition of 2^22 rows / 100 M edges of a graph with N * 2^22 nodes; --cut (default 0.1) of a
-partition's edges point anywhere in the graph, the rest stay inside it (N = 1 is then exactly the
-single-GPU graph).  Per layer the rows of H = X.W that other partitions reference are exchanged
+partition's edges leave it and land on the boundary nodes (--boundary, default 0.2 of the rows) of
+the other partitions, the rest stay inside it -- the shape a graph partitioner leaves behind (N = 1
+is exactly the single-GPU graph).  Per layer the rows of H = X.W that other partitions reference are exchanged
 over xGMI (RCCL all-to-all of halo rows; --exchange allgather / --cut 1.0 = every row) and
 aggregated locally (sgracex1_amd/dist.py).
 """
@@ -52,6 +53,9 @@ def parse():
     ap.add_argument("--cut", type=float, default=0.1,
                     help="N > 1: share of a partition's edges whose column is drawn from the whole graph "
                          "(1.0 = no locality at all, every H row is a halo row)")
+    ap.add_argument("--boundary", type=float, default=0.2,
+                    help="N > 1: share of a partition's nodes that edges from other partitions may point at "
+                         "(1.0 = any node: every remote row ends up in somebody's halo)")
     ap.add_argument("--exchange", choices=("halo-overlap", "halo", "allgather"), default=None,
                     help="N > 1: rows of H exchanged per layer (default: halo-overlap = halo rows travel while the "
                          "own-partition edges are aggregated; allgather when --cut >= 0.5)")
@@ -60,7 +64,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(torch, graphs, ops, wl, rank, world, device, cut=1.0):
+def make_inputs(torch, graphs, ops, wl, rank, world, device, cut=1.0, boundary=1.0):
     """Synthetic graph + features + weights of the stated shape, generated on the device."""
     n, hidden, f_in = wl["n"], wl["hidden"], wl["f_in"]
     seed = 12345 + rank
@@ -75,13 +79,17 @@ def make_inputs(torch, graphs, ops, wl, rank, world, device, cut=1.0):
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         row = torch.randint(0, n, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
-        # a partitioned graph: an edge leaves its row's partition with probability `cut` (then its
-        # column is uniform over all nodes), otherwise it stays inside the partition
-        col_any = torch.randint(0, n_global, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        # a partitioned graph: an edge leaves its row's partition with probability `cut`; it then lands in
+        # another partition, on one of that partition's boundary nodes (its first `boundary` share of rows --
+        # a partitioner leaves most nodes interior); otherwise the edge stays inside the partition
+        n_bnd = max(1, int(n * boundary))
+        peer = torch.randint(0, world - 1, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
+        peer = peer + (peer >= rank).to(torch.int64)                    # any partition but the own one
+        col_far = peer * n + torch.randint(0, n_bnd, (wl["edges"],), generator=g, device=device, dtype=torch.int64)
         col_own = torch.randint(0, n, (wl["edges"],), generator=g, device=device, dtype=torch.int64) + rank * n
         leaves = torch.rand(wl["edges"], generator=g, device=device) < cut
-        col = torch.where(leaves, col_any, col_own)
-        del col_any, col_own, leaves
+        col = torch.where(leaves, col_far, col_own)
+        del col_far, col_own, leaves, peer
         loops = torch.arange(n, device=device, dtype=torch.int64)
         row = torch.cat([row, loops])
         col = torch.cat([col, loops + rank * n])
@@ -191,7 +199,9 @@ def main():
             dist.init_process_group(backend_name)
 
     wl = WORKLOADS[args.workload]
-    A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device, cut=args.cut)
+    if args.cut >= 0.5:
+        args.boundary = 1.0                      # "no locality": any node of any partition
+    A, X, W1t, W2t = make_inputs(torch, graphs, ops, wl, rank, world, device, cut=args.cut, boundary=args.boundary)
     exchange = args.exchange or ("allgather" if args.cut >= 0.5 else "halo-overlap")
     n, hidden = wl["n"], wl["hidden"]
     nnz = A.nnz
@@ -335,7 +345,7 @@ def main():
                    (f"RCCL all-to-all of halo rows of H per layer ({sum(halo.recv_counts)} rows received per rank)"
                     + (", overlapped with the aggregation of the own-partition edges" if exchange == "halo-overlap" else "")
                     if halo is not None else "RCCL all-gather of H per layer"),
-                   "cut": None if world == 1 else args.cut},
+                   "cut": None if world == 1 else args.cut, "boundary": None if world == 1 else args.boundary},
         "roofline": {"bound": "hbm", "kernel": "spmm_kernel<f16,8,8> (A.H aggregation"
                      + (", own-partition pass)" if (world > 1 and exchange == "halo-overlap") else ")"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
