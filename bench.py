@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--exact", action="store_true",
                     help="N = 1: run both layers in SGX_ACC_REF_HALF with SPMM_BLOCK 4 -- the reference's half arithmetic, "
                          "bit for bit (the setting that reproduces its csim log)")
-    ap.add_argument("--cpu-sample-frac", type=float, default=0.25)
+    ap.add_argument("--cpu-sample-frac", type=float, default=1.0)
     ap.add_argument("--cut", type=float, default=0.1,
                     help="N > 1: share of a partition's edges whose column is drawn from the whole graph "
                          "(1.0 = no locality at all, every H row is a halo row)")
