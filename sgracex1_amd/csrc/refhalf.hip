@@ -313,7 +313,8 @@ int sgx_refhalf_csr(int spmm_block, int threads, int relu, int n_rows, int n_col
     const unsigned long long t_bytes = (unsigned long long)n_cols * (unsigned long long)ldt * 2ull;
     int lpr = sgx_next_pow2((n_feat + 7) / 8);
     if (lpr > 64) lpr = 64;
-    if (lpr >= 4 && (uintptr_t)table % 16 == 0 && (ldt * 2) % 16 == 0 && t_bytes <= kOOBRow && n_cols > 0) {
+    if (lpr < 4) lpr = 4;                 // a piece must span the 4 partial sums; narrow rows leave lanes of the group idle
+    if ((uintptr_t)table % 16 == 0 && (ldt * 2) % 16 == 0 && t_bytes <= kOOBRow && n_cols > 0) {
         const unsigned tb = (unsigned)t_bytes, lb = (unsigned)(ldt * 2);
         switch (lpr) {
         case 4: return launch_rows<4>(spmm_block, threads, relu, n_rows, n_feat, rowPtr, columnIndex, values, table, tb, lb, out, ldo, s);
