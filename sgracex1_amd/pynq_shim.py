@@ -138,7 +138,8 @@ class RegisterMap:
 
     _DEFAULTS = dict(gemm_mode=0, relu=0, gat_mode=0, N_adj=0, M_adj=0, M_fea=0, P_w=0, bias_count=0,
                      array_c_adjust=0, zero_point_lhs=0, zero_point_rhs=0, zero_point_dst=0, clamp_max=0,
-                     clamp_min=0, nnz_adj1=0, nnz_fea1=0)
+                     clamp_min=0, nnz_adj1=0, nnz_fea1=0,
+                     max_fea=0)     # read back by SG.py:506 (largest |H| seen by the quantiser, 16 fractional bits): not tracked, reads 0
 
     def __init__(self, ip):
         object.__setattr__(self, "_regs", dict(self._DEFAULTS))
