@@ -6,6 +6,11 @@ that code written against `import config; config.acc = 1` keeps working:
 
 Each flag is declared once in `_FLAGS` below with what it means HERE; the module then publishes
 them as plain module attributes.  Only the flags that reach the GPU hot path are live.
+
+Defaults differ from the reference's shipped board files in one respect: those run the quantised
+bitstream (`fake_quantization = 1`, `hardware_quantize = 1`, `w_qbits = 8` on the boards, `1` in
+demo/emulation/config.py), here the layers are unquantised until these flags are set -- the fp16 /
+fp32 layer is the path this package is about.  `reference_board_defaults()` applies the boards' values.
 """
 import numpy as _np
 
@@ -38,6 +43,12 @@ _FLAGS = {
 
 globals().update({name: default for name, (default, _doc) in _FLAGS.items()})
 P_w = hidden_channels  # noqa: F821  (published by the line above)
+
+
+def reference_board_defaults(w_qbits_value=8):
+    """The values of demo/{rfsoc42,ultra96,zcu104}/config.py: accelerator on, quantised arithmetic, float32 buffers."""
+    g = globals()
+    g.update(acc=1, accb=0, fake_quantization=1, hardware_quantize=1, w_qbits=w_qbits_value, float_type=_np.float32)
 
 
 def describe():
