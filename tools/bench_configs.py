@@ -184,6 +184,26 @@ def main():
                 "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9})
 
     if "c5" in want:
+        # the SGRACE library's own setting: float32 buffers, 8-bit quantised arithmetic (the reference's board
+        # configs ship with fake_quantization = hardware_quantize = 1, w_qbits = 8)
+        from sgracex1_amd import quant
+        n, P = 169_343, 256
+        A32 = graphs.uniform_graph(n, 2_330_000, seed=5, dtype=torch.float32)
+        X32 = torch.rand((n, 128), generator=gen, device=dev)
+        Wt32 = (torch.rand((P, 128), generator=gen, device=dev) * 2 - 1) / P ** 0.5
+        att32 = (torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.3
+        D32 = torch.empty((n, P), dtype=torch.float32, device=dev)
+        A32.plan
+        qc = quant.constants(8)
+        rec = {}
+        for name, kw in (("gcn", {}), ("gat", {"gat_attention": att32})):
+            rec[f"ms_layer_fp32_{name}"] = timed(lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, **kw), 50)
+            rec[f"ms_layer_fp32_{name}_8bit_quantised"] = timed(
+                lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, **kw), 50)
+        report("c5 in the SGRACE library's setting (float32 buffers, w_qbits 8)", A32, rec, {"f_in": 128, "width": P})
+        del A32, X32, D32
+
+    if "c5" in want:
         # the same layer on a power-law graph (R-MAT, 2^18 nodes): hub rows take the split path of the plan
         n, P = 1 << 18, 256
         A = graphs.rmat_graph(18, 2_330_000, seed=6)
