@@ -59,6 +59,18 @@ __global__ __launch_bounds__(kBlock) void gat_scores_kernel(int n_rows, int n_fe
 
 __device__ __forceinline__ float leaky(float x, float alpha) { return x > 0.0f ? x : x * alpha; }
 
+// ReLU (SG.py:660-661), then the quantised layer's deq_o factor on fp32 outputs (SG.py:666-667; 0 = off)
+template <typename T>
+__device__ __forceinline__ T gat_finish(float sum, int relu, float out_scale)
+{
+    T v = Elem<T>::from_f32(sum);
+    v = (!relu || v > (T)0) ? v : (T)0;
+    if constexpr (sizeof(T) == 4) {
+        if (out_scale != 0.0f) v = v * out_scale;
+    }
+    return v;
+}
+
 // merge two online-softmax states (m, l); (-inf, 0) is the empty state
 __device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, float l2)
 {
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
     T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
-    const float *__restrict__ fill, int long_threshold)
+    const float *__restrict__ fill, int long_threshold, float out_scale)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -160,10 +172,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = dead ? ((col0 + i < n_feat) ? fill[col0 + i] : 0.0f) : acc[i] * inv_l;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                T v = Elem<T>::from_f32(acc[i]);
-                out[i] = (!relu || v > (T)0) ? v : (T)0;           // SG.py:660-661
-            }
+            for (int i = 0; i < VEC; ++i) out[i] = gat_finish<T>(acc[i], relu, out_scale);
             T *drow = D + r * ldd;
             if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
                 *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void gat_split_finalize_kernel(
     int n_long, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ long_row,
     const int32_t *__restrict__ long_first, const float *__restrict__ pacc, int ldp, const float *__restrict__ pm,
     const float *__restrict__ pl, T *__restrict__ D, int64_t ldd, int relu, const float *__restrict__ fill,
-    float *__restrict__ row_m, float *__restrict__ row_l)
+    float *__restrict__ row_m, float *__restrict__ row_l, float out_scale)
 {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (int64_t)n_long * n_feat) return;
@@ -289,8 +298,7 @@ __global__ __launch_bounds__(kBlock) void gat_split_finalize_kernel(
         a += pacc[(int64_t)t * ldp + j] * w;
     }
     float out = l > 0.0f ? a / l : (fill ? fill[j] : 0.0f);
-    T v = Elem<T>::from_f32(out);
-    D[(int64_t)long_row[i] * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
+    D[(int64_t)long_row[i] * ldd + j] = gat_finish<T>(out, relu, out_scale);
     if (j % f_head == 0) { row_m[(int64_t)i * n_heads + h] = m; row_l[(int64_t)i * n_heads + h] = l; }
 }
 
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
     T *__restrict__ D, int64_t ldd, int relu, float *__restrict__ E, float *__restrict__ S, int vec_store,
     const float *__restrict__ fill, int share, int long_threshold, const int32_t *__restrict__ task_row,
     const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1, float *__restrict__ pacc, int ldp,
-    float *__restrict__ pm, float *__restrict__ pl)
+    float *__restrict__ pm, float *__restrict__ pl, float out_scale)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -455,10 +463,7 @@ __global__ __launch_bounds__(kBlock) void gat_aggregate_heads_kernel(
                 for (int i = 0; i < VEC; ++i) acc[i] = (col0 + i < n_feat) ? fill[col0 + i] : 0.0f;
             }
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                T v = Elem<T>::from_f32(acc[i]);
-                out[i] = (!relu || v > (T)0) ? v : (T)0;
-            }
+            for (int i = 0; i < VEC; ++i) out[i] = gat_finish<T>(acc[i], relu, out_scale);
             T *drow = D + r * ldd;
             if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
                 *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
@@ -508,6 +513,7 @@ struct GatArgs {
     void *D;
     float *E, *S, *s;
     const float *fill;
+    float out_scale;           // deq_o of the quantised layer on fp32 outputs (0 = off)
     const sgx_plan *plan;      // long rows -> split path
     float *split;              // scratch of the split path, behind the scores / column means
     int vec_ok, vec_store;
@@ -545,19 +551,20 @@ int gat_launch_one(const GatArgs &a)
         hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, false>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows,
                            a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
                            a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill,
-                           share, thr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
+                           share, thr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, a.out_scale);
         SGX_LAUNCH_CHECK();
         if (thr > 0) {
             const unsigned tgrid = (unsigned)((hp->n_tasks + rows_per_block - 1) / rows_per_block);
             hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, true>), dim3(tgrid), dim3(kBlock), 0, a.stream,
                                hp->n_tasks, a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val,
                                (const T *)a.Wh, a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, nullptr,
-                               a.vec_store, nullptr, share, 0, hp->task_row, hp->task_e0, hp->task_e1, pacc, ldp, pm, pl);
+                               a.vec_store, nullptr, share, 0, hp->task_row, hp->task_e0, hp->task_e1, pacc, ldp, pm, pl,
+                               a.out_scale);
             SGX_LAUNCH_CHECK();
             const int64_t total = (int64_t)hp->n_long * a.n_feat;
             hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock),
                                0, a.stream, hp->n_long, a.n_feat, a.n_heads, f_head, hp->long_row, hp->long_first, pacc, ldp,
-                               pm, pl, (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l);
+                               pm, pl, (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
             SGX_LAUNCH_CHECK();
             if (a.S) {
                 hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(hp->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols,
@@ -585,7 +592,7 @@ int gat_launch_one(const GatArgs &a)
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                            a.stream, p->n_long, a.n_feat, 1, a.n_feat, p->long_row, p->long_first, pacc, ldp, pm, pl, (T *)a.D,
-                           a.ldd, a.relu, a.fill, row_m, row_l);
+                           a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
         SGX_LAUNCH_CHECK();
         if (a.S) {
             hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols, 1,
@@ -596,7 +603,7 @@ int gat_launch_one(const GatArgs &a)
     }
     hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_cols, a.n_feat,
                        a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
-                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill, long_thr);
+                       (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill, long_thr, a.out_scale);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -645,6 +652,15 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
                                  void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan, float *s_scratch,
                                  void *stream)
 {
+    return sgx_gat_aggregate_ep(dtype, relu, fill_dead_rows, n_rows, n_cols, n_feat, n_heads, alpha, rowPtr, columnIndex, values,
+                                Wh, ldh, attention, D, ldd, E, S, plan, s_scratch, (hipStream_t)stream, 0.0f);
+}
+
+int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
+                         const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
+                         const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
+                         float *s_scratch, hipStream_t stream, float out_scale)
+{
     if (n_heads < 1) n_heads = 1;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
     if (n_rows < 0 || n_cols < n_rows || n_feat < 1 || ldh < n_feat || ldd < n_feat) return SGX_ERR_SHAPE;
@@ -660,7 +676,7 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
     a.relu = relu; a.n_rows = n_rows; a.n_cols = n_cols; a.n_feat = n_feat; a.n_heads = n_heads; a.alpha = alpha;
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
-    a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = (hipStream_t)stream;
+    a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = stream; a.out_scale = out_scale;
     a.fill = nullptr;
     a.plan = uses_split(plan) ? plan : nullptr;
     a.split = s_scratch + base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);

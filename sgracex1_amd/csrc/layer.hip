@@ -138,46 +138,46 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         }
     }
 
+    // the quantised layer's two rounding steps ride on the stores of the stages (SG.py:603-616, :666-667)
+    sgx_epilogue ep_h = sgx_no_epilogue(), ep_d = sgx_no_epilogue();
+    if (q) {
+        ep_h = sgx_requant_epilogue(q->scale_fea, q->internal_bits);
+        ep_d.out_scale = q->deq_factor;
+    }
+
     // stage 1: H = X . W          (loop_fea, K.cpp:2932)
     if (d->gemm_mode == 0) {
         rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, B, d->M_fea, W, ldh, s);         // B [P][M] -> W [M][ldh]
         if (rc != SGX_OK) return rc;
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, /*relu*/0, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,
                              d->columnIndex_fea, values_fea, W, ldh, H, ldh, d->plan_fea, scratch, c.s_bytes, s, nullptr,
-                             nullptr, 0, /*fea_stage*/true, thread_count(d->fea_threads));
+                             nullptr, 0, /*fea_stage*/true, thread_count(d->fea_threads), ep_h);
     } else if (d->acc_mode == SGX_ACC_REF_HALF && thread_count(d->fea_threads) > 1) {
         if (d->dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
         if (ldh > d->P_w) SGX_HIP_CHECK(hipMemsetAsync(H, 0, (size_t)d->M_adj * ldh * sizeof(f16), s));
         rc = sgx_refhalf_dense(d->spmm_block, d->fea_threads, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
                                H, ldh, s);
     } else {
-        rc = sgx_xw_dense(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
-                          H, ldh, s);
+        rc = sgx_xw_dense_ep(d->dtype, d->acc_mode, d->spmm_block, d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea,
+                             H, ldh, s, ep_h);
     }
     if (rc != SGX_OK) return rc;
-    if (q) {                                                                            // SG.py:603-616
-        rc = sgx_requantize(d->M_adj, d->P_w, ldh, (float *)H, q->scale_fea, q->internal_bits, s);
-        if (rc != SGX_OK) return rc;
-    }
 
     // stage 2: D = act(A . H)     (loop_adj, K.cpp:3339) or the edge-softmax aggregate (SG.py:634-661)
     if (d->ev_agg_begin) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_begin, s));
     if (d->gat_mode) {
         if (!attention) return SGX_ERR_NULL;
-        rc = sgx_gat_aggregate(d->dtype, d->relu, d->gat_fill_dead_rows, d->N_adj, d->M_adj, d->P_w, d->gat_heads, d->alpha,
-                               d->rowPtr_adj, d->columnIndex_adj,
-                               values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S, d->plan_adj,
-                               (float *)(ws + c.g_off), s);
+        rc = sgx_gat_aggregate_ep(d->dtype, d->relu, d->gat_fill_dead_rows, d->N_adj, d->M_adj, d->P_w, d->gat_heads, d->alpha,
+                                  d->rowPtr_adj, d->columnIndex_adj,
+                                  values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S, d->plan_adj,
+                                  (float *)(ws + c.g_off), s, ep_d.out_scale);
     } else {
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,
                              d->rowPtr_adj, d->columnIndex_adj, values_adj, H, ldh, d->D, d->P_w, d->plan_adj,
-                             scratch, c.s_bytes, s, nullptr, nullptr, 0, /*fea_stage*/false, thread_count(d->adj_threads));
+                             scratch, c.s_bytes, s, nullptr, nullptr, 0, /*fea_stage*/false, thread_count(d->adj_threads), ep_d);
     }
     if (rc != SGX_OK) return rc;
-    if (q) {                                                                            // SG.py:666-667
-        rc = sgx_scale_f32((int64_t)d->N_adj * d->P_w, (float *)d->D, q->deq_factor, s);
-        if (rc != SGX_OK) return rc;
-    }
+
     if (d->ev_agg_end) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_end, s));
     return SGX_OK;
 }

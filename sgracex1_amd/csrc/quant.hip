@@ -3,6 +3,9 @@
 // integers and put back on a fractional grid, H = X.W is shifted, clipped and rounded to the
 // width of the internal pipeline, the aggregate is rescaled by deq_o.  Everything stays fp32, as
 // in the reference; these kernels only reproduce its rounding points, one fp32 operation each.
+// Inside sgx_layer_forward the re-quantisation of H and the deq_o factor ride on the stores of the two
+// stages (sgx_epilogue, sgx_internal.h); the kernels here quantise the operands and serve the standalone
+// entry points.
 //
 // fp contraction is off for this file: `1 / s * x + z` is a rounded product followed by a
 // rounded sum in the reference (two torch ops), not one fma.
@@ -61,13 +64,6 @@ __global__ __launch_bounds__(kBlock) void requantize_kernel(int64_t n_rows, int 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void scale_kernel(int64_t n, float *__restrict__ D, float factor)
-{
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = gid; i < n; i += stride) D[i] = D[i] * factor;
-}
-
 int grid_for(int64_t n)
 {
     int64_t b = (n + kBlock - 1) / kBlock;
@@ -90,31 +86,28 @@ extern "C" int sgx_fake_quantize(int is_signed, int qbits, float inv_scale, floa
     return SGX_OK;
 }
 
+sgx_epilogue sgx_requant_epilogue(int scale_fea, int internal_bits)
+{
+    sgx_epilogue ep = sgx_no_epilogue();
+    ep.rq_shift = 1.0f / (float)(1 << scale_fea);                            // exact
+    const double full = (double)(1u << internal_bits);
+    ep.rq_bound = (float)((full - 1.0) / full);                              // a_max of SG.py:609, as torch casts it
+    double p = 1.0;                                                          // static_cast<float>(std::pow(10, d))
+    for (int i = 0; i < internal_bits - 1; ++i) p *= 10.0;
+    ep.rq_ten_pow = (float)p;
+    return ep;
+}
+
 extern "C" int sgx_requantize(int n_rows, int n_feat, int64_t ld, float *H, int scale_fea, int internal_bits, void *stream)
 {
     if (n_rows < 0 || n_feat < 1 || ld < n_feat) return SGX_ERR_SHAPE;
     if (scale_fea < 0 || scale_fea > 30 || internal_bits < 1 || internal_bits > 30) return SGX_ERR_UNSUPPORTED;
     if (n_rows == 0) return SGX_OK;
     if (!H) return SGX_ERR_NULL;
-    const float shift = 1.0f / (float)(1 << scale_fea);                       // exact
-    const double full = (double)(1u << internal_bits);
-    const float bound = (float)((full - 1.0) / full);                        // a_max of SG.py:609, as torch casts it
-    float ten_pow = 1.0f;                                                    // static_cast<float>(std::pow(10, d))
-    {
-        double p = 1.0;
-        for (int i = 0; i < internal_bits - 1; ++i) p *= 10.0;
-        ten_pow = (float)p;
-    }
+    const sgx_epilogue ep = sgx_requant_epilogue(scale_fea, internal_bits);
     hipLaunchKernelGGL(requantize_kernel, dim3(grid_for((int64_t)n_rows * n_feat)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (int64_t)n_rows, n_feat, ld, H, shift, bound, ten_pow);
+                       (int64_t)n_rows, n_feat, ld, H, ep.rq_shift, ep.rq_bound, ep.rq_ten_pow);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
 
-int sgx_scale_f32(int64_t n, float *D, float factor, hipStream_t s)
-{
-    if (n <= 0) return SGX_OK;
-    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, D, factor);
-    SGX_LAUNCH_CHECK();
-    return SGX_OK;
-}

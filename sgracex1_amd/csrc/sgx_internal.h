@@ -54,6 +54,25 @@ static inline int64_t sgx_ldh(int dtype, int P) {
     return (int64_t)((P + per16 - 1) / per16) * per16;
 }
 
+// Epilogue of the quantised layer, applied where a stage stores fp32 results (fp16 instantiations ignore it):
+//   X.W stage : H = round_decimals(clip(H * rq_shift, +-rq_bound), d) with rq_ten_pow = 10^d   (0 = off; SG.py:607-616)
+//   A.H stage : D = act(sum) * out_scale                                                      (0 = off; SG.py:666-667)
+// One fp32 operation per rounding point of the reference, as in quant.hip.
+struct sgx_epilogue {
+    float out_scale, rq_shift, rq_bound, rq_ten_pow;
+};
+static inline sgx_epilogue sgx_no_epilogue() { return sgx_epilogue{0.0f, 0.0f, 0.0f, 0.0f}; }
+sgx_epilogue sgx_requant_epilogue(int scale_fea, int internal_bits);          // quant.hip
+// the re-quantisation of one fp32 value of H; contraction must stay off around it
+__device__ __forceinline__ float sgx_requant_value(float v, const sgx_epilogue &ep)
+{
+#pragma clang fp contract(off)
+    v = v * ep.rq_shift;
+    v = v < -ep.rq_bound ? -ep.rq_bound : v;
+    v = v > ep.rq_bound ? ep.rq_bound : v;
+    return rintf(v * ep.rq_ten_pow) / ep.rq_ten_pow;
+}
+
 // SGX_ACC_REF_HALF stages (refhalf.hip), fp16 only
 int sgx_refhalf_csr(int spmm_block, int threads, int relu, int n_rows, int n_cols, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
                     const void *values, const void *table, int64_t ldt, void *out, int64_t ldo, hipStream_t s);
@@ -65,7 +84,12 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const void *H, int64_t ldh, void *D, int64_t ldd,
                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
                     const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0,
-                    bool fea_stage = false, int ref_threads = 1);
+                    bool fea_stage = false, int ref_threads = 1, sgx_epilogue ep = sgx_no_epilogue());
 
-// D *= factor, fp32 (the deq_o step of the quantised layer, quant.hip)
-int sgx_scale_f32(int64_t n, float *D, float factor, hipStream_t s);
+// sgx_xw_dense / sgx_gat_aggregate with the quantised layer's epilogue (the public entry points pass none)
+int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
+                    const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep);
+int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
+                         const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
+                         const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
+                         float *s_scratch, hipStream_t stream, float out_scale);

@@ -161,17 +161,28 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
     }
 }
 
+// what one fp32 sum becomes in D: the stage's epilogue (fp32 outputs of the quantised layer only), then ReLU
+template <typename T>
+__device__ __forceinline__ T finish_value(float sum, int relu, const sgx_epilogue &ep)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (ep.rq_ten_pow != 0.0f) sum = sgx_requant_value(sum, ep);
+    }
+    T v = Elem<T>::from_f32(sum);
+    v = (!relu || v > (T)0) ? v : (T)0;                    // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
+    if constexpr (sizeof(T) == 4) {
+        if (ep.out_scale != 0.0f) v = v * ep.out_scale;
+    }
+    return v;
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_feat, const float *acc, int relu,
-                                          bool vec_store)
+                                          bool vec_store, const sgx_epilogue &ep)
 {
     T out[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        T v = Elem<T>::from_f32(acc[i]);
-        // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
-        out[i] = (!relu || v > (T)0) ? v : (T)0;
-    }
+    for (int i = 0; i < VEC; ++i) out[i] = finish_value<T>(acc[i], relu, ep);
     (void)vec_store;
     if (VEC > 1 && col0 + VEC <= n_feat) {
         // one 16-byte store even when the row of D is only element-aligned (P_w = 41, 47 ...):
@@ -204,7 +215,7 @@ __device__ __forceinline__ void spmm_body(
     const int32_t *__restrict__ row_order,
     int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
     float *__restrict__ partial, int ldp,
-    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc)
+    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc, sgx_epilogue ep)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
     constexpr int LANE_COLS = CPL * VEC;          // columns per lane
@@ -285,7 +296,7 @@ __device__ __forceinline__ void spmm_body(
 #pragma unroll
                 for (int j = 0; j < CPL; ++j)
                     if (col0 + j * VEC < n_feat)
-                        store_row<T, VEC>(D + r * ldd, col0 + j * VEC, n_feat, acc + j * VEC, relu, vec_store != 0);
+                        store_row<T, VEC>(D + r * ldd, col0 + j * VEC, n_feat, acc + j * VEC, relu, vec_store != 0, ep);
             }
         }
     }
@@ -297,10 +308,10 @@ __device__ __forceinline__ void spmm_body(
         int64_t ldd, int relu, int long_threshold, int vec_store, const int32_t *__restrict__ row_order,          \
         int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,  \
         float *__restrict__ partial, int ldp, const float *__restrict__ acc_in, float *__restrict__ acc_out,       \
-        int64_t ld_acc
+        int64_t ld_acc, sgx_epilogue ep
 #define SGX_SPMM_ARGS                                                                                            \
     n_rows, n_feat, rowptr, col, val, H, h_bytes, ld_bytes, D, ldd, relu, long_threshold, vec_store, row_order,  \
-        split_blocks, n_tasks, task_e0, task_e1, partial, ldp, acc_in, acc_out, ld_acc
+        split_blocks, n_tasks, task_e0, task_e1, partial, ldp, acc_in, acc_out, ld_acc, ep
 
 // Two entry points over the one body, so that a profile tells the stages apart:
 // spmm_kernel = the A.H aggregation (loop_adj), xw_sparse_kernel = X.W with a CSR X (loop_fea, the
@@ -321,7 +332,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void spmm_split_finalize_kernel(
     int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
     const float *__restrict__ partial, int ldp, T *__restrict__ D, int64_t ldd, int relu,
-    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc)
+    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc, sgx_epilogue ep)
 {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t total = (int64_t)n_long * n_feat;
@@ -331,8 +342,7 @@ __global__ __launch_bounds__(kBlock) void spmm_split_finalize_kernel(
     float s = acc_in ? acc_in[row * ld_acc + j] : 0.0f;
     for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
     if (acc_out) { acc_out[row * ld_acc + j] = s; return; }
-    T v = Elem<T>::from_f32(s);
-    D[row * ldd + j] = (!relu || v > (T)0) ? v : (T)0;
+    D[row * ldd + j] = finish_value<T>(s, relu, ep);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -354,6 +364,7 @@ struct LaunchArgs {
     float *acc_out;
     int64_t ld_acc;
     bool fea_stage;           // launched for X.W (sgx_xw_sparse): same body under its own kernel name
+    sgx_epilogue ep;
     hipStream_t stream;
 };
 
@@ -383,14 +394,14 @@ int launch_one_impl(const LaunchArgs &a)
                            a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
                            a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order, split_blocks, n_tasks,
                            n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, a.partial, a.ldp, a.acc_in,
-                           a.acc_out, a.ld_acc);
+                           a.acc_out, a.ld_acc, a.ep);
         SGX_LAUNCH_CHECK();
     }
     if (n_tasks > 0) {
         const int64_t total = (int64_t)p->n_long * a.n_feat;
         hipLaunchKernelGGL((spmm_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, a.partial,
-                           a.ldp, (T *)a.D, a.ldd, a.relu, a.acc_in, a.acc_out, a.ld_acc);
+                           a.ldp, (T *)a.D, a.ldd, a.relu, a.acc_in, a.acc_out, a.ld_acc, a.ep);
         SGX_LAUNCH_CHECK();
     }
     return SGX_OK;
@@ -449,7 +460,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
                     const void *H, int64_t ldh, void *D, int64_t ldd,
                     const sgx_plan *plan, void *scratch, size_t scratch_bytes, hipStream_t stream,
-                    const float *acc_in, float *acc_out, int64_t ld_acc, bool fea_stage, int ref_threads)
+                    const float *acc_in, float *acc_out, int64_t ld_acc, bool fea_stage, int ref_threads, sgx_epilogue ep)
 {
     (void)spmm_block;
     if (n_rows < 0 || n_cols < 0 || n_feat < 1 || ldh < n_feat) return SGX_ERR_SHAPE;
@@ -477,7 +488,7 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.H = H;
     a.h_bytes = big ? 0u : (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es); a.big = big;
     a.D = D; a.ldd = ldd; a.plan = plan; a.stream = stream;
-    a.acc_in = acc_in; a.acc_out = acc_out; a.ld_acc = ld_acc; a.fea_stage = fea_stage;
+    a.acc_in = acc_in; a.acc_out = acc_out; a.ld_acc = ld_acc; a.fea_stage = fea_stage; a.ep = ep;
     a.partial = (float *)scratch;
     a.ldp = (int)sgx_align_up((size_t)n_feat, 4);
     if (plan && plan->n_tasks > 0) {

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
 template <int NT, int MT>
 __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
     int n_rows, int M, int P, int p_base, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt,
-    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned)
+    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned, sgx_epilogue ep)
 {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -163,6 +163,10 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
         for (int nt = 0; nt < NT; ++nt) {
             const int n = p_base + nt * 16 + 4 * lq;
             float *dst = H + m * ldh + n;
+            if (ep.rq_ten_pow != 0.0f) {                       // quantised layer: H is re-quantised as it is produced
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][nt][j] = sgx_requant_value(acc[mt][nt][j], ep);
+            }
             if (h_aligned && n + 4 <= ldh) {
                 *reinterpret_cast<f32x4 *>(dst) = acc[mt][nt];
             } else {
@@ -331,7 +335,7 @@ int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const v
 
 template <int NT, int MT>
 int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
-                int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s)
+                int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep)
 {
     const int64_t rows_per_block = (int64_t)MT * 16 * (kBlock / 64);
     const unsigned grid = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
@@ -340,7 +344,7 @@ int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, 
                            (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, xa, wa, ha);
     else
         hipLaunchKernelGGL((xw_dense_f32_kernel<NT, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, p_base,
-                           (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha);
+                           (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha, ep);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -350,11 +354,19 @@ int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, 
 extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                             const void *Wt, int64_t ldw, void *H, int64_t ldh, void *stream)
 {
+    return sgx_xw_dense_ep(dtype, acc_mode, spmm_block, n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, (hipStream_t)stream,
+                           sgx_no_epilogue());
+}
+
+int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
+                    const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep)
+{
+    if (ep.rq_ten_pow != 0.0f && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;      // the quantised layer is fp32
     if (n_rows < 0 || M_fea < 1 || P < 1 || ldx < M_fea || ldw < M_fea || ldh < P) return SGX_ERR_SHAPE;
     if (n_rows == 0) return SGX_OK;
     if (!X || !Wt || !H) return SGX_ERR_NULL;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream;
     if (acc_mode == SGX_ACC_REF_HALF) {
         // the reference's sequential half arithmetic (refhalf.hip)
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
@@ -375,11 +387,11 @@ extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows,
         const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);
         const int nt = (cols + 15) / 16;
         int rc;
-        if (nt <= 1)       rc = launch_tile<1, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
-        else if (nt <= 2)  rc = launch_tile<2, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
-        else if (nt <= 4)  rc = launch_tile<4, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
-        else if (nt <= 8)  rc = launch_tile<8, 2>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
-        else               rc = launch_tile<16, 1>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s);
+        if (nt <= 1)       rc = launch_tile<1, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
+        else if (nt <= 2)  rc = launch_tile<2, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
+        else if (nt <= 4)  rc = launch_tile<4, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
+        else if (nt <= 8)  rc = launch_tile<8, 2>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
+        else               rc = launch_tile<16, 1>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
         if (rc != SGX_OK) return rc;
     }
     return SGX_OK;
