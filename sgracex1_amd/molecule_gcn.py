@@ -43,6 +43,12 @@ def as_csr(adj, dtype):
     return ops.Csr.from_dense(adj, dtype)
 
 
+def feature_csr(x, dtype):
+    """CSR of a (dense) feature matrix, kept on the tensor while it is unchanged: node features are the same
+    tensor in every epoch, and the conversion costs a device->host sync (plus, in backward, a transpose)."""
+    return ops.cached_on(x, ("fea_csr", dtype), lambda: as_csr(x.detach(), dtype))
+
+
 class RPYNQ(torch.autograd.Function):
     """MOL cell 16: identity forward (the ReLU already ran inside the layer), backward zeroes the
     gradient where the layer's output is exactly 0."""
@@ -80,7 +86,7 @@ class FPYNQ(torch.autograd.Function):
         if dense:
             fea = input.detach().to(ACC_DTYPE).contiguous()
         else:
-            fea = as_csr(input.detach(), ACC_DTYPE)
+            fea = feature_csr(input, ACC_DTYPE)
         output_acc = my_ip.run_layer(A, fea, Wt)
         ctx.adj = A
         ctx.fea_csr = None if dense else fea
@@ -216,10 +222,8 @@ class GCN_PYNQ(torch.nn.Module):
             # pynq_adj = to_dense_adj(edge_index)._to_sparse_csr() of the notebook, built from the
             # edge list directly (same CSR, no dense N x N intermediate); the batch of an epoch loop is
             # the same tensor every time, so the result is kept
-            key = (edge_index.data_ptr(), edge_index.shape[1], x.shape[0], edge_index._version)
-            if getattr(self, "_adj_key", None) != key:
-                self._adj_key, self._adj_csr = key, ops.csr_from_edge_index(edge_index, x.shape[0], dtype=ACC_DTYPE)
-            adj = self._adj_csr
+            adj = ops.cached_on(edge_index, ("adj_csr", x.shape[0], ACC_DTYPE),
+                                lambda: ops.csr_from_edge_index(edge_index, x.shape[0], dtype=ACC_DTYPE))
         else:
             adj = torch.squeeze(to_dense_adj(edge_index, num_nodes=x.shape[0]))
         dense, relu = 0, 1

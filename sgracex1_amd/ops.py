@@ -47,6 +47,17 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def cached_on(tensor, key, build):
+    """Derived data (a CSR, a transposed pattern ...) kept ON the tensor object it was built from, so that it
+    lives exactly as long as that tensor and can never be handed to another tensor that happens to reuse the
+    address; an in-place change of the tensor (its version counter) rebuilds it."""
+    store = tensor.__dict__.setdefault("_sgx_cache", {})
+    hit = store.get(key)
+    if hit is None or hit[0] != tensor._version:
+        hit = store[key] = (tensor._version, build())
+    return hit[1]
+
+
 _workspaces = {}
 
 

@@ -124,18 +124,14 @@ class FPYNQ_GAT(torch.autograd.Function):
                 layern = 2 if layern == 1 else 1
                 _program_quant_registers(my_ip.register_map, qc)
             rm = my_ip.register_map
-            A = self._csr if isinstance(adj, torch.Tensor) else adj
-            A = A.to(dt)
+            A = self._csr.to(dt)
             Wt = weights.detach().t().to(dt).contiguous()
             fea = input.detach()
             if int(rm.gemm_mode) == 0:
                 # the CSR of a feature matrix is rebuilt only when the tensor changes (node features are fixed
                 # over the epochs of a node-classification run)
-                key = (fea.data_ptr(), fea._version, tuple(fea.shape), dt)
-                if getattr(self, "_fea_key", None) != key:
-                    self._fea_csr = ops.Csr.from_dense(fea if fea.layout == torch.strided else fea.to_dense(), dt)
-                    self._fea_key = key
-                fea = self._fea_csr
+                fea = ops.cached_on(input, ("fea_csr", dt), lambda: ops.Csr.from_dense(
+                    fea if fea.layout == torch.strided else fea.to_dense(), dt))
             else:
                 fea = fea.to(dt).contiguous()
             my_ip.alpha = self.alpha
@@ -275,7 +271,18 @@ class GATConv_SGRACE(Module):
             rm = self.my_ip.register_map
             rm.relu, rm.gemm_mode, rm.gat_mode = relu, dense, compute_attention
             rm.nnz_adj1 = nnz_adj
-            self._csr = _edge_csr(adj, edge_index, norm, input.shape[0], _torch_dtype())
+            # the CSR (with its row plan, quantised copy and dead-row check) is rebuilt only when the edge list
+            # changes: the demo passes the same graph every epoch
+            if isinstance(adj, ops.Csr):
+                self._csr = adj.to(_torch_dtype())
+            else:
+                # kept on the edge list together with the `norm` it was built from (held, so that its identity
+                # cannot be taken over by another tensor): rebuilt when either changes
+                slot = ops.cached_on(edge_index, ("csr", input.shape[0], _torch_dtype()), dict)
+                if slot.get("norm") is not norm or slot.get("norm_version") != norm._version:
+                    slot.update(norm=norm, norm_version=norm._version,
+                                csr=_edge_csr(None, edge_index, norm, input.shape[0], _torch_dtype()))
+                self._csr = slot["csr"]
         return self.fn(self.my_ip, self, adj, nnz_adj, input, self.weight, self.attention, self.out_features,
                        self.dropout, relu)
 
@@ -295,16 +302,15 @@ class GAT_PYNQ(Module):
         self.conv22 = GATConv_SGRACE(hidden_channels * head_count, hidden_channels, 1)
         self.reluh = Relu_SGRACE()
         self.lin = torch.nn.Linear(hidden_channels, num_classes)
-        self._graph = None
 
     def forward(self, x, edge_index):
-        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), x.size(0))
-        if self._graph is None or self._graph[0] != key:          # the graph is normalised once, not per call
+        def normalise():                                          # once per graph, not per call
             ei, norm = sym_norm2(edge_index, x.size(0))
             adj = _edge_csr(None, ei, norm, x.size(0), _torch_dtype()) if config.acc == 1 else \
                 torch.sparse_coo_tensor(ei, norm, (x.size(0), x.size(0)))
-            self._graph = (key, ei, norm, adj)
-        _, ei, norm, adj = self._graph
+            return ei, norm, adj
+
+        ei, norm, adj = ops.cached_on(edge_index, ("sym_norm2", x.size(0), config.acc, _torch_dtype()), normalise)
         x = self.att2(config.compute_attention, 0, 1, x, ei, norm, adj)
         x = self.reluh(x)
         x = self.conv22(config.compute_attention, 1, 0, x, ei, norm, adj)
