@@ -39,6 +39,19 @@ def _dev2d(t, name):
     return t
 
 
+def _out(out, rows, cols, dtype, device, name="out"):
+    """A caller-provided result buffer: [rows, >= cols] of the right element type on the right device, unit
+    column stride (rows may be padded).  The library writes through the raw pointer, so a wrong buffer must
+    be refused here."""
+    if out is None:
+        return torch.empty((rows, cols), dtype=dtype, device=device)
+    _dev2d(out, name)
+    if out.dtype != dtype or out.device != device or out.shape[0] != rows or out.shape[1] != cols:
+        raise ValueError(f"{name} must be a [{rows}, {cols}] {dtype} tensor on {device} "
+                         f"(got {tuple(out.shape)} {out.dtype} on {out.device})")
+    return out
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -214,8 +227,7 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_
     if adj.val.dtype != H.dtype:
         raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
     n_feat = H.shape[1] if n_feat is None else n_feat
-    if out is None:
-        out = torch.empty((adj.n_rows, n_feat), dtype=H.dtype, device=H.device)
+    out = _out(out, adj.n_rows, n_feat, H.dtype, H.device)
     plan = adj.plan if (use_plan and adj.wants_plan) else None
     sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
     scratch = _workspace(H.device, sbytes) if sbytes else None
@@ -239,8 +251,8 @@ def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_p
         if acc_in.dtype != torch.float32 or acc_in.shape != (adj.n_rows, n_feat):
             raise ValueError("acc_in must be float32 [n_rows, n_feat]")
     acc_out = torch.empty((adj.n_rows, n_feat), dtype=torch.float32, device=H.device) if partial_out else None
-    if not partial_out and out is None:
-        out = torch.empty((adj.n_rows, n_feat), dtype=H.dtype, device=H.device)
+    if not partial_out:
+        out = _out(out, adj.n_rows, n_feat, H.dtype, H.device)
     plan = adj.plan if (use_plan and adj.wants_plan) else None
     sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
     scratch = _workspace(H.device, sbytes) if sbytes else None
@@ -326,8 +338,9 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     if use_plan and adj.wants_plan:
         d.plan_adj = adj.plan.handle
     d.B = Wt.data_ptr()
-    if out is None:
-        out = torch.empty((adj.n_rows, P), dtype=Wt.dtype, device=Wt.device)
+    out = _out(out, adj.n_rows, P, Wt.dtype, Wt.device)
+    if out.stride(0) != P:
+        raise ValueError("the layer writes D densely ([N_adj][P_w], K.cpp:802): `out` must not have padded rows")
     d.D = out.data_ptr()
     E = S = None
     if gat_attention is not None:
@@ -391,8 +404,7 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
     att = _dev(attention, "attention").reshape(-1)
     if adj.val.dtype != Wh.dtype or att.dtype != Wh.dtype:
         raise TypeError("adjacency values, Wh and the attention vector must share one element type (MM.h:129-139)")
-    if out is None:
-        out = torch.empty((adj.n_rows, F), dtype=Wh.dtype, device=Wh.device)
+    out = _out(out, adj.n_rows, F, Wh.dtype, Wh.device)
     E = S = None
     heads = int(heads)
     if F % heads or att.numel() != 2 * F:

@@ -286,3 +286,26 @@ def test_sgrace_demo_model_trains_on_the_kernels(attention, qbits, floor):
         (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type,
          config.device) = old
         sgrace.init_SGRACE()
+
+
+def test_result_buffers_are_checked_before_the_library_writes_through_them():
+    from sgracex1_amd import graphs, ops
+    dev = torch.device("cuda")
+    A = graphs.uniform_graph(500, 3000, seed=2)
+    H = torch.rand((500, 64), device=dev).half()
+    ok = torch.empty((500, 64), dtype=torch.float16, device=dev)
+    assert ops.spmm(A, H, out=ok) is ok
+    padded = torch.zeros((500, 72), dtype=torch.float16, device=dev)
+    view = padded[:, :64]
+    ops.spmm(A, H, out=view)                                         # padded rows are fine for the stage ...
+    assert torch.equal(view, ok) and not padded[:, 64:].any()
+    for bad in (torch.empty((500, 32), dtype=torch.float16, device=dev), torch.empty((499, 64), dtype=torch.float16, device=dev),
+                torch.empty((500, 64), dtype=torch.float32, device=dev), torch.empty((500, 64), dtype=torch.float16),
+                torch.empty((64, 500), dtype=torch.float16, device=dev).t()):
+        with pytest.raises(ValueError):
+            ops.spmm(A, H, out=bad)
+    Wt = torch.rand((64, 64), device=dev).half()
+    with pytest.raises(ValueError):
+        ops.layer_forward(A, H, Wt, out=view)                        # ... the layer writes D densely
+    with pytest.raises(ValueError):
+        ops.gat_aggregate(A, H, torch.rand(128, device=dev).half(), out=torch.empty((500, 65), dtype=torch.float16, device=dev))
