@@ -226,6 +226,8 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_
     code = dtype_code(H.dtype)
     if adj.val.dtype != H.dtype:
         raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
+    if H.shape[0] < adj.n_cols:
+        raise ValueError(f"H has {H.shape[0]} rows, the adjacency refers to {adj.n_cols} columns")
     n_feat = H.shape[1] if n_feat is None else n_feat
     out = _out(out, adj.n_rows, n_feat, H.dtype, H.device)
     plan = adj.plan if (use_plan and adj.wants_plan) else None
@@ -245,6 +247,8 @@ def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_p
     code = dtype_code(H.dtype)
     if adj.val.dtype != H.dtype:
         raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
+    if H.shape[0] < adj.n_cols:
+        raise ValueError(f"H has {H.shape[0]} rows, the adjacency refers to {adj.n_cols} columns")
     n_feat = H.shape[1]
     if acc_in is not None:
         _dev(acc_in, "acc_in")
