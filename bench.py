@@ -260,6 +260,9 @@ def main():
             b1 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p1, D1))
             b2 = sdist.Backend(backend.xw, lambda a, t, r: timed_spmm(a, t, r, p2, D2))
             if overlap:
+                if os.environ.get("SGX_BENCH_TEST_FAIL_OVERLAP"):       # test hook: exercise the fallback below
+                    raise RuntimeError("injected failure of the overlapped exchange")
+
                 def first_pass(pair):
                     def run(a, t):
                         if pair is not None:
@@ -287,8 +290,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(0, False)
+    # warm-up; for N > 1 it doubles as the trial of the overlapped exchange: should that path raise on this
+    # node, every rank drops to the one-pass halo exchange together (same structures) instead of losing the run
+    failed = 0
+    try:
+        for _ in range(args.warmup):
+            step(0, False)
+        torch.cuda.synchronize()
+    except Exception as exc:                       # noqa: BLE001 -- any failure of the trial, reported below
+        if not (world > 1 and overlap):
+            raise
+        failed = 1
+        print(f"[bench rank {rank}] overlapped halo exchange failed in warm-up: {exc!r}", file=sys.stderr, flush=True)
+    if world > 1 and overlap:
+        flag = torch.tensor([failed], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            overlap, exchange, agg_nnz = False, "halo", nnz
+            for _ in range(args.warmup):
+                step(0, False)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -84,6 +84,20 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     assert expect in rec["config"]["exchange"]
 
 
+def test_bench_falls_back_to_the_one_pass_halo_exchange():
+    """If the overlapped exchange raises in warm-up, all ranks agree to run the one-pass halo form."""
+    import json
+    env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SGX_BENCH_TEST_FAIL_OVERLAP="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29990 + os.getpid() % 9),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "small"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "overlapped" not in rec["config"]["exchange"] and "all-to-all of halo rows" in rec["config"]["exchange"]
+    assert "injected failure" in out.stderr and rec["value"] > 0
+
+
 def test_bench_single_gpu_line_has_the_contract_fields():
     """`python bench.py` (N = 1) on the small workload: one JSON line with the driver's fields, the
     roofline object timed on the launch stream, and the CPU baseline from the oracle port."""
