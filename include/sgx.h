@@ -75,9 +75,14 @@ typedef struct sgx_plan sgx_plan;
  * used with (sizes the partial-sum scratch it owns). */
 int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
                     void *stream);
+/* The same with the cut chosen by the caller: rows over `long_threshold` edges are split into tasks of `chunk`
+ * edges (0 = the defaults: 4096 / 4096, which suit the A.H aggregation; the GAT aggregate keeps a softmax state
+ * per step and runs best with 512 / 512).  Matrices under 2^20 entries always use 64 / 64. */
+int sgx_plan_create_ex(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int long_threshold, int chunk,
+                       void *stream);
 void sgx_plan_destroy(sgx_plan *plan);
 /* number of rows that take the split path, and the edge count above which a row does (for reports /
- * tests): 512, or 64 for matrices under 2^20 stored entries, whose run time is the longest row's
+ * tests): 4096 by default, 64 for matrices under 2^20 stored entries, whose run time is the longest row's
  * chain of dependent steps */
 int sgx_plan_long_rows(const sgx_plan *plan);
 int sgx_plan_long_threshold(const sgx_plan *plan);

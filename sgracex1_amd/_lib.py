@@ -20,7 +20,7 @@ SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
-    "sgx_plan_create", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_long_threshold", "sgx_plan_natural_utilization",
+    "sgx_plan_create", "sgx_plan_create_ex", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_long_threshold", "sgx_plan_natural_utilization",
     "sgx_plan_reordered",
     "sgx_fake_quantize", "sgx_requantize",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
@@ -83,6 +83,8 @@ def _load():
     c_int, c_i64, vp, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
     lib.sgx_plan_create.argtypes = [ctypes.POINTER(vp), vp, c_int, c_int, vp]
     lib.sgx_plan_create.restype = c_int
+    lib.sgx_plan_create_ex.argtypes = [ctypes.POINTER(vp), vp, c_int, c_int, c_int, vp]
+    lib.sgx_plan_create_ex.restype = c_int
     lib.sgx_plan_destroy.argtypes = [vp]
     lib.sgx_plan_destroy.restype = None
     lib.sgx_plan_long_rows.argtypes = [vp]

@@ -155,8 +155,13 @@ extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_
 // across layers and epochs (the reference re-streams the same CSR for every tile and layer),
 // so this runs once per adjacency.
 // ---------------------------------------------------------------------------------------
-static const int kLongThreshold = 512;   // rows with more edges than this take the split path
-static const int kChunk = 512;           // edges per split task (8 pieces of 64 edges per wavefront)
+// Rows with more edges than the threshold take the split path, in tasks of `chunk` edges.  Measured on the
+// R-MAT S-100M aggregation (threshold = chunk): 512: 2.20 ms, 1024-2048: 2.10, 3072: 2.00, 4096: 1.94,
+// 6144: 2.04, 8192: 2.32 -- a lane group walks a 4096-edge row in 512 steps while the degree-ordered schedule
+// keeps its wavefront full, and every task costs a partial row and a finalize read.  (The GAT aggregate, with
+// its softmax state per step, prefers 512: sgx_plan_create_ex.)
+static const int kLongThreshold = 4096;
+static const int kChunk = 4096;
 // Small matrices finish in microseconds and their time IS the longest row's chain of dependent
 // steps (Cora: 168 edges = 21 steps on one lane group), so there rows are cut much earlier: a
 // 64-edge task is one step for every lane group of its wavefront.
@@ -167,7 +172,14 @@ static const float kReorderBelow = 0.7f; // natural-order lane-group utilisation
 extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows, int n_feat_hint, void *stream)
 {
     (void)n_feat_hint;
+    return sgx_plan_create_ex(out, rowPtr, n_rows, 0, 0, stream);
+}
+
+extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_rows, int long_threshold_arg, int chunk_arg,
+                                  void *stream)
+{
     if (!out || !rowPtr) return SGX_ERR_NULL;
+    if (long_threshold_arg < 0 || chunk_arg < 0) return SGX_ERR_SHAPE;
     if (n_rows < 0) return SGX_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     std::vector<int32_t> rp((size_t)n_rows + 1);
@@ -175,8 +187,20 @@ extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows
     SGX_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<int32_t> long_row, long_first, task_row, task_e0, task_e1;
     const bool small = rp[(size_t)n_rows] < kSmallNnz;
-    const int long_threshold = small ? kSmallThreshold : kLongThreshold;
-    const int chunk = small ? kSmallChunk : kChunk;
+    int long_threshold = small ? kSmallThreshold : kLongThreshold;
+    int chunk = small ? kSmallChunk : kChunk;
+    if (!small && long_threshold_arg >= 8) {                          // the caller's cut (large matrices only)
+        long_threshold = long_threshold_arg / 8 * 8;
+        chunk = chunk_arg >= 8 ? chunk_arg / 8 * 8 : long_threshold;
+    }
+    if (const char *t = getenv("SGX_PLAN_LONG_THRESHOLD")) {          // tuning overrides (tools/plan_probe)
+        const int v = atoi(t);
+        if (v >= 8) long_threshold = chunk = v / 8 * 8;
+    }
+    if (const char *t = getenv("SGX_PLAN_CHUNK")) {
+        const int v = atoi(t);
+        if (v >= 8) chunk = v / 8 * 8;
+    }
     for (int r = 0; r < n_rows; ++r) {
         const int deg = rp[r + 1] - rp[r];
         if (deg <= long_threshold) continue;

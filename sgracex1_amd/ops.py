@@ -87,11 +87,11 @@ def _workspace(device, nbytes):
 class Plan:
     """Row schedule of one CSR matrix (sgx_plan): which rows are split across wavefronts."""
 
-    def __init__(self, rowptr, n_feat_hint=64):
+    def __init__(self, rowptr, long_threshold=0, chunk=0):
         _dev(rowptr, "rowptr")
         h = ctypes.c_void_p()
-        check(lib.sgx_plan_create(ctypes.byref(h), _ptr(rowptr), rowptr.numel() - 1, n_feat_hint, _stream()),
-              "sgx_plan_create")
+        check(lib.sgx_plan_create_ex(ctypes.byref(h), _ptr(rowptr), rowptr.numel() - 1, int(long_threshold), int(chunk),
+                                     _stream()), "sgx_plan_create_ex")
         self._h = h
         self.n_rows = rowptr.numel() - 1
 
@@ -171,6 +171,14 @@ class Csr:
         if self._plan is None:
             self._plan = Plan(self.rowptr)
         return self._plan
+
+    @property
+    def gat_plan(self):
+        """The schedule for the edge-softmax aggregate: hub rows are cut at 512 edges there (the default plan's
+        4096 suits the plain aggregation; measured in DESIGN.md 4)."""
+        if getattr(self, "_gat_plan", None) is None:
+            self._gat_plan = Plan(self.rowptr, 512, 512)
+        return self._gat_plan
 
     @property
     def wants_plan(self):
@@ -340,7 +348,7 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
         d.gat_fill_dead_rows = int(adj.has_dead_rows)
     d.rowPtr_adj, d.columnIndex_adj, d.values_adj = adj.rowptr.data_ptr(), adj.col.data_ptr(), adj.val.data_ptr()
     if use_plan and adj.wants_plan:
-        d.plan_adj = adj.plan.handle
+        d.plan_adj = (adj.gat_plan if gat_attention is not None else adj.plan).handle
     d.B = Wt.data_ptr()
     out = _out(out, adj.n_rows, P, Wt.dtype, Wt.device)
     if out.stride(0) != P:
@@ -418,7 +426,7 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
         E = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
         S = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
     fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
-    plan = adj.plan.handle if (use_plan and adj.wants_plan) else None
+    plan = adj.gat_plan.handle if (use_plan and adj.wants_plan) else None
     s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, fill, plan) // 4, dtype=torch.float32, device=Wh.device)
     check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, heads, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
