@@ -93,12 +93,15 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
             // the next iteration's (column, value) pairs are requested before this iteration's gathers
             fetch(base + (PIECES + p) * stride + sub, c_next[p], a_next[p]);
         }
+#ifndef SGX_SPMM_ADJ_INFLIGHT
+#define SGX_SPMM_ADJ_INFLIGHT 8
+#endif
 #ifndef SGX_SPMM_FEA_INFLIGHT
 #define SGX_SPMM_FEA_INFLIGHT 4
 #endif
         // edges of one piece whose gathers go together (the loop leaves a piece after the last group that
         // holds a valid edge, so a smaller group wastes fewer slots on short rows)
-        constexpr int kInFlight = (STYLE == 1 ? SGX_SPMM_FEA_INFLIGHT : 8) / CPL;
+        constexpr int kInFlight = (STYLE == 1 ? SGX_SPMM_FEA_INFLIGHT : SGX_SPMM_ADJ_INFLIGHT) / CPL;
         constexpr int UNR = LPR < kInFlight ? LPR : kInFlight;
 #pragma unroll 1
         for (int t0 = 0; t0 < LPR; t0 += UNR) {
