@@ -111,3 +111,49 @@ def test_row_partition_and_slices():
     val = torch.ones(40)
     r, c, v = D.slice_rows(rp, col, val, 2, 5)
     assert r.tolist() == [0, 1, 10, 11] and c.tolist() == list(range(10, 21)) and v.numel() == 11
+
+
+def test_cached_on_lives_with_the_tensor_and_follows_its_version():
+    """Derived data is kept on the source tensor: rebuilt after an in-place change, never shared with
+    another tensor object (not even one that reuses the storage address)."""
+    import torch
+    from sgracex1_amd import ops
+    calls = []
+
+    def build():
+        calls.append(1)
+        return len(calls)
+
+    t = torch.arange(6)
+    assert ops.cached_on(t, "k", build) == 1 and ops.cached_on(t, "k", build) == 1 and len(calls) == 1
+    assert ops.cached_on(t, ("other", 3), build) == 2                  # another key on the same tensor
+    t.add_(1)                                                          # version counter moves
+    assert ops.cached_on(t, "k", build) == 3
+    u = t.detach()                                                     # same storage, another tensor object
+    assert ops.cached_on(u, "k", build) == 4 and ops.cached_on(t, "k", build) == 3
+
+
+def test_quantiser_registers_round_trip_through_the_register_map():
+    """init-time / per-call register writes of the reference (SG.py:334-365, :476, :1745-1838) decoded back
+    into the constants the C ABI takes; absent registers mean the plain layer."""
+    import numpy as np
+    from sgracex1_amd import pynq_shim, quant
+    from sgracex1_amd.sgrace import _program_quant_registers
+    ip = pynq_shim.IP(device="cpu")
+    assert ip.quant_from_registers() is None
+    for bits, beta in ((8, 255), (4, 15), (2, 2), (1, 1)):
+        c = quant.constants(bits)
+        ip.register_map.beta_qu = beta
+        _program_quant_registers(ip.register_map, c)
+        q = ip.quant_from_registers()
+        assert (q.w_qbits, q.scale_fea, q.internal_quantization) == (bits, c.scale_fea, c.internal_quantization)
+        for name in ("w_s", "a_s", "f_s"):
+            assert np.float32(1 / getattr(q, name)) == np.float32(1 / getattr(c, name))
+        assert np.float32(q.deq_o) == np.float32(c.deq_o)
+        s = q.as_struct(nnz_adj=10, nnz_fea=4, adj_done=True)
+        assert s.qbits == bits and s.flags == 1 and s.nnz_adj == 10 and s.nnz_fea == 4
+    ip.register_map.beta_qu = 7
+    import pytest
+    with pytest.raises(ValueError):
+        ip.quant_from_registers()
+    assert ip.register_map.max_fea == 0
