@@ -530,3 +530,28 @@ def test_fp16_subnormals_are_not_flushed(sgx):
     H = (torch.arange(1, n * p + 1, dtype=torch.float32).reshape(n, p) % 9 + 1) * 2.0 ** -12
     out = sgx.spmm(A, H.half().to(dev), relu=False)
     assert torch.equal(out.cpu(), (H * 2.0 ** -12).half()) and (out > 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("P", [64, 128, 24])
+def test_sparse_features_with_very_short_rows(sgx, oracle, dtype, P):
+    """X with ~3 entries per row and a row plan: the X.W stage runs with two 16-byte chunks per lane
+    (CPL = 2, chosen below 5 entries per row) in its loads-first form -- against the exact-math oracle."""
+    rng = np.random.default_rng(P)
+    n, m = 40_000, 500
+    deg = rng.integers(0, 7, n)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = rng.integers(0, m, rp[-1]).astype(np.int32)
+    va = rng.standard_normal(rp[-1]).astype(np.float32)
+    Wt = (rng.standard_normal((P, m)) * 0.1).astype(np.float32)
+    if dtype == torch.float16:
+        va, Wt = _h(oracle, va), _h(oracle, Wt)
+    eye = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n, np.float32))
+    X = _csr(sgx, (rp, ci, va), m, dtype)
+    assert X.nnz >= 8192 and X.nnz / n < 5 and X.wants_plan
+    got = sgx.layer_forward(_csr(sgx, eye, n, dtype), X, _dev(Wt, dtype), relu=0)
+    want = oracle.layer_f64(0, 0, eye, (rp, ci, va), Wt, h_round=2 if dtype == torch.float16 else 1)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, **tol)
+    assert not got[torch.as_tensor(deg == 0, device="cuda")].any()
