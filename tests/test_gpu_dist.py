@@ -89,7 +89,7 @@ def test_bench_falls_back_to_the_one_pass_halo_exchange():
     import json
     env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SGX_BENCH_TEST_FAIL_OVERLAP="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(29990 + os.getpid() % 9),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 90),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--workload", "small"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
