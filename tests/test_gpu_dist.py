@@ -73,7 +73,7 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     the default partitioned graph (halo exchange) and the no-locality case (all-gather)."""
     env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90 + len(extra)),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 80 + len(expect) % 17),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--workload", "small"] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
