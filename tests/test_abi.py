@@ -151,3 +151,17 @@ def test_package_fails_loudly_without_the_library(tmp_path):
     out = subprocess.run([sys.executable, "-c", "import sgracex1_amd.ops"], cwd=ROOT, env=dict(env, SGX_LIB_PATH=str(bogus)),
                          capture_output=True, text=True)
     assert out.returncode != 0 and "Error" in out.stderr
+
+
+def test_integration_md_stub_matches_the_header(L):
+    """The ctypes stub printed in INTEGRATION.md is field for field the struct of include/sgx.h."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class sgx_layer_desc(ctypes.Structure)"):]
+    block = block[:block.index("\n\nsgx.sgx_layer_workspace_bytes")]
+    scope = {"ctypes": ctypes}
+    exec(block, scope)                                                 # defines sgx_layer_desc from the document
+    doc = scope["sgx_layer_desc"]
+    assert ctypes.sizeof(doc) == ctypes.sizeof(L.LayerDesc)
+    assert [n for n, _ in doc._fields_] == [n for n, _ in L.LayerDesc._fields_]
+    for name, _ in doc._fields_:
+        assert getattr(doc, name).offset == getattr(L.LayerDesc, name).offset, name
