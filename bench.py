@@ -347,6 +347,27 @@ def main():
         except (ValueError, OSError):
             traffic = None
 
+    # the roof a plain copy reaches on this very device (SURVEY 8d asks for it next to the nominal 8 TB/s)
+    copy_gbps = None
+    if rank == 0:
+        src = torch.empty(1 << 29, dtype=torch.float16, device=device)     # 1 GiB read + 1 GiB written
+        dst = torch.empty_like(src)
+        from sgracex1_amd._lib import check, lib
+        import ctypes
+
+        def copy():
+            check(lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), src.numel() * 2, ctypes.c_void_p(stream)), "sgx_stream_copy")
+
+        for _ in range(2):
+            copy()
+        cb, ce = Event(), Event()
+        cb.record(stream)
+        for _ in range(5):
+            copy()
+        ce.record(stream)
+        copy_gbps = 5 * 2 * src.numel() * 2 / (cb.elapsed_ms(ce) * 1e-3) / 1e9
+        del src, dst
+
     ms_per_step = elapsed / args.steps * 1e3
     line = {
         "metric": "edges aggregated/sec, 2-layer GCN forward",
@@ -371,7 +392,8 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                      "avg_launch_ms": agg_avg_ms, "min_launch_ms": agg_ms[0], "launches_timed": len(agg_ms),
-                     "agg_edges_per_s": agg_nnz / (agg_avg_ms * 1e-3)},
+                     "agg_edges_per_s": agg_nnz / (agg_avg_ms * 1e-3),
+                     "stream_copy_GBps_this_device": copy_gbps},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)

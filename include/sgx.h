@@ -307,6 +307,11 @@ int sgx_readout_mean_linear(int dtype, int n_graphs, int F, int C, const void *X
 int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
                            void *stream);
 
+/* A plain streaming copy (16 bytes per lane, non-temporal), the kernel the attainable HBM rate of a device is
+ * measured with next to the nominal 8 TB/s (bench.py reports it as roofline.stream_copy_GBps_this_device).
+ * bytes must be a multiple of 16, both pointers 16-byte aligned. */
+int sgx_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
+
 /* hipEvent_t helpers for the profiling taps of sgx_layer_desc (handles travel as void*), so that
  * a host that does not link the HIP runtime itself can time launches on the library's runtime.
  * sgx_event_elapsed_ms waits for `end` and returns the milliseconds between the two events. */

@@ -309,3 +309,19 @@ def test_result_buffers_are_checked_before_the_library_writes_through_them():
         ops.layer_forward(A, H, Wt, out=view)                        # ... the layer writes D densely
     with pytest.raises(ValueError):
         ops.gat_aggregate(A, H, torch.rand(128, device=dev).half(), out=torch.empty((500, 65), dtype=torch.float16, device=dev))
+
+
+def test_stream_copy_moves_every_byte():
+    """sgx_stream_copy (the kernel bench.py measures the attainable HBM rate with): sizes around the 4-deep
+    unrolled stride, bit-equal; misaligned and ragged requests are refused."""
+    import ctypes
+    from sgracex1_amd._lib import lib
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n16 in (1, 255, 256 * 16 * 256 * 4 - 1, 256 * 16 * 256 * 4 + 77, 3_000_001):
+        src = torch.randint(-2**31, 2**31 - 1, (n16 * 4,), dtype=torch.int32, device="cuda")
+        dst = torch.zeros_like(src)
+        assert lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), n16 * 16, stream) == 0
+        assert torch.equal(dst, src)
+    assert lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), 0, stream) == 0
+    assert lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), 24, stream) != 0
+    assert lib.sgx_stream_copy(dst.data_ptr() + 4, src.data_ptr(), 32, stream) != 0
