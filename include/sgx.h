@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 101
+#define SGX_VERSION 102
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -127,6 +127,11 @@ int sgx_fake_quantize(int is_signed, int qbits, float inv_scale, float zero, int
 int sgx_requantize(int n_rows, int n_feat, int64_t ld, float *H, int scale_fea, int internal_bits, void *stream);
 
 /* ---- the layer: replaces mmult_top / kernelmult1 (K.cpp:3762, :3969; KH:13-58) ------ */
+typedef enum sgx_layer_order {
+    SGX_ORDER_REFERENCE = 0,        /* D = act(A.(X.W))                                    */
+    SGX_ORDER_AGGREGATE_FIRST = 1   /* D = act((A.X).W)                                    */
+} sgx_layer_order;
+
 typedef struct sgx_layer_desc {
     /* AXI-Lite scalars of the reference, same names (K.cpp:3777-3790, MMN cell 13) */
     int32_t gemm_mode;   /* 0: X is CSR (rowPtr_fea, columnIndex_fea, values_fea)
@@ -192,6 +197,13 @@ typedef struct sgx_layer_desc {
 
     /* optional: run the layer with the quantised arithmetic above (NULL = plain fp16/fp32 layer) */
     const sgx_quant *quant;
+
+    /* sgx_layer_order.  The reference always forms H = X.W first (loop_fea feeds loop_adj, K.cpp:3629-3752).
+     * With a dense X narrower than the output (M_fea < P_w: ogbn-products' 100 -> 256) aggregating first,
+     * D = act((A.X).W), gathers M_fea instead of P_w columns per edge: the same sums in another association,
+     * one rounding to the storage type in between as in the reference's order (Z = A.X in place of H).
+     * Only gemm_mode 1, gat_mode 0, SGX_ACC_F32, no quant block; SGX_ERR_UNSUPPORTED otherwise. */
+    int32_t order;
 } sgx_layer_desc;
 
 size_t sgx_layer_workspace_bytes(const sgx_layer_desc *desc);

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_HERE, "csrc", "libsgx
 
 SGX_F16, SGX_F32 = 0, 1
 SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
+SGX_ORDER_REFERENCE, SGX_ORDER_AGGREGATE_FIRST = 0, 1      # sgx_layer_order
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
@@ -71,6 +72,7 @@ class LayerDesc(ctypes.Structure):
         ("plan_adj", ctypes.c_void_p), ("plan_fea", ctypes.c_void_p),
         ("ev_agg_begin", ctypes.c_void_p), ("ev_agg_end", ctypes.c_void_p),
         ("quant", ctypes.POINTER(Quant)),
+        ("order", ctypes.c_int32),
     ]
 
 

@@ -25,6 +25,17 @@ Carve carve(const sgx_layer_desc *d)
     const size_t es = sgx_elem_size(d->dtype);
     const size_t ldh = (size_t)sgx_ldh(d->dtype, d->P_w);
     size_t off = 0;
+    if (d->order == SGX_ORDER_AGGREGATE_FIRST) {
+        // Z = A.X  [N_adj][ldz] takes the place of H; split-row partials are M_fea wide
+        const size_t ldz = (size_t)sgx_ldh(d->dtype, d->M_fea);
+        c.h_off = off; c.h_bytes = sgx_align_up((size_t)d->N_adj * ldz * es, 256); off += c.h_bytes;
+        c.w_off = off; c.w_bytes = 0;
+        c.s_off = off; c.s_bytes = sgx_spmm_scratch_bytes(d->plan_adj, d->M_fea); off += c.s_bytes;
+        c.g_off = off; c.g_bytes = 0;
+        c.q_off = off; c.q_bytes = 0; c.qb = c.qx = c.qa = c.qt = 0;
+        c.total = off;
+        return c;
+    }
     c.h_off = off; c.h_bytes = sgx_align_up((size_t)d->M_adj * ldh * es, 256); off += c.h_bytes;
     c.w_off = off; c.w_bytes = d->gemm_mode == 0 ? sgx_align_up((size_t)d->M_fea * ldh * es, 256) : 0; off += c.w_bytes;
     size_t s1 = sgx_spmm_scratch_bytes(d->plan_adj, d->P_w);
@@ -51,6 +62,10 @@ int check_desc(const sgx_layer_desc *d)
     if (d->N_adj < 0 || d->M_adj < 0 || d->M_fea < 1 || d->P_w < 1) return SGX_ERR_SHAPE;
     if (d->dtype != SGX_F16 && d->dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
     if (d->gemm_mode != 0 && d->gemm_mode != 1) return SGX_ERR_UNSUPPORTED;   // 2 = backward offload, not in the public HLS
+    if (d->order != SGX_ORDER_REFERENCE && d->order != SGX_ORDER_AGGREGATE_FIRST) return SGX_ERR_UNSUPPORTED;
+    if (d->order == SGX_ORDER_AGGREGATE_FIRST &&
+        (d->gemm_mode != 1 || d->gat_mode || d->quant || d->acc_mode != SGX_ACC_F32))
+        return SGX_ERR_UNSUPPORTED;
     if (d->quant) {
         const sgx_quant *q = d->quant;
         if (d->dtype != SGX_F32 || d->acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;   // SG.py:1545: float32 buffers
@@ -109,6 +124,20 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     void *W = ws + c.w_off;
     void *scratch = c.s_bytes ? ws + c.s_off : nullptr;
     const int64_t ldh = sgx_ldh(d->dtype, d->P_w);
+
+    if (d->order == SGX_ORDER_AGGREGATE_FIRST) {
+        // Z = A.X (M_fea columns gathered per edge), then D = act(Z.W) on the matrix cores with the ReLU on its stores
+        if (!d->values_adj && d->M_adj > 0) return SGX_ERR_NULL;
+        const int64_t ldz = sgx_ldh(d->dtype, d->M_fea);
+        if (d->ev_agg_begin) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_begin, s));
+        rc = sgx_spmm_launch(d->dtype, d->acc_mode, 1, /*relu*/0, d->N_adj, d->M_adj, d->M_fea, d->rowPtr_adj,
+                             d->columnIndex_adj, d->values_adj, d->values_fea, d->M_fea, H, ldz, d->plan_adj, scratch,
+                             c.s_bytes, s, nullptr, nullptr, 0);
+        if (rc != SGX_OK) return rc;
+        if (d->ev_agg_end) SGX_HIP_CHECK(hipEventRecord((hipEvent_t)d->ev_agg_end, s));
+        return sgx_xw_dense_ep(d->dtype, d->acc_mode, 1, d->N_adj, d->M_fea, d->P_w, H, ldz, d->B, d->M_fea, d->D, d->P_w, s,
+                               sgx_no_epilogue(), d->relu);
+    }
 
     // quantised layer: the operands are replaced by their quantised copies (SG.py:574, :593, :624-626)
     const void *B = d->B, *values_fea = d->values_fea, *values_adj = d->values_adj, *attention = d->attention;

@@ -102,6 +102,7 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
         // edges of one piece whose gathers go together (the loop leaves a piece after the last group that
         // holds a valid edge, so a smaller group wastes fewer slots on short rows)
         constexpr int kInFlight = (STYLE == 1 ? SGX_SPMM_FEA_INFLIGHT : SGX_SPMM_ADJ_INFLIGHT) / CPL;
+        static_assert(kInFlight >= 1, "SGX_SPMM_*_INFLIGHT must be at least the largest CPL (4): a group of 0 edges never advances");
         constexpr int UNR = LPR < kInFlight ? LPR : kInFlight;
 #pragma unroll 1
         for (int t0 = 0; t0 < LPR; t0 += UNR) {
@@ -498,7 +499,14 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
         if (!scratch || scratch_bytes < sgx_spmm_scratch_bytes(plan, n_feat)) return SGX_ERR_WORKSPACE;
     }
     const int per16 = (int)(16 / es);
-    const bool vec_gather = ((uintptr_t)H % 16 == 0) && ((ldh * es) % 16 == 0);
+    // 16-byte gathers need rows that start on a dword: buffer loads take dword-aligned addresses (gfx950 runs in
+    // unaligned-access mode) and are range-checked dword by dword, so a chunk that runs past the end of a row reads
+    // the neighbouring row's first elements into lanes that are never stored, and past the end of the table zeros.
+    // Rows on odd halves (P_w = 41 unpadded) would pair their last element with a dword outside the table, and the
+    // 64-bit pointer path has no range check: those keep one element per lane unless rows are 16-byte aligned.
+    const bool rows16 = ((uintptr_t)H % 16 == 0) && ((ldh * es) % 16 == 0);
+    const bool rows4 = !big && ((uintptr_t)H % 4 == 0) && ((ldh * es) % 4 == 0);
+    const bool vec_gather = rows16 || rows4;
     a.vec_store = ((uintptr_t)D % 16 == 0) && ((ldd * es) % 16 == 0);
     if (vec_gather) {
         int slots = sgx_next_pow2((n_feat + per16 - 1) / per16);

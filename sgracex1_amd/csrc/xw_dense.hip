@@ -27,6 +27,9 @@ constexpr int kBlock = 256;
 // global loads only need element alignment, so the fragment is still ONE dwordx4 load through an
 // under-aligned vector type.
 typedef f16x8 f16x8_u __attribute__((aligned(2)));
+
+// K.cpp:2586-2590 on a rounded value: keep when (v > 0 || relu == 0), else +0
+__device__ __forceinline__ f16 relu_f16(f16 v, int relu) { return (!relu || v > (f16)0) ? v : (f16)0; }
 typedef f32x4 f32x4_u __attribute__((aligned(4)));
 
 // 8 consecutive K elements of one row, zero beyond k_end
@@ -58,7 +61,7 @@ __device__ __forceinline__ f32x4 load_k4(const float *__restrict__ row, int k, i
 template <int NT, int MT>
 __global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
     int n_rows, int M, int P, int p_base, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt, int64_t ldw,
-    f16 *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned)
+    f16 *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned, int relu)
 {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
             const int n = p_base + nt * 16 + 4 * lq;       // 4 consecutive columns of H
             f16x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
+            for (int j = 0; j < 4; ++j) o[j] = relu_f16((f16)acc[mt][nt][j], relu);
             f16 *dst = H + m * ldh + n;
             if (h_aligned && n + 4 <= ldh) {
                 *reinterpret_cast<f16x4 *>(dst) = o;        // columns P..ldh-1 receive exact zeros
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
 template <int NT, int MT>
 __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
     int n_rows, int M, int P, int p_base, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt,
-    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned, sgx_epilogue ep)
+    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned, sgx_epilogue ep, int relu)
 {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -167,6 +170,10 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[mt][nt][j] = sgx_requant_value(acc[mt][nt][j], ep);
             }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][nt][j] = acc[mt][nt][j] > 0.0f ? acc[mt][nt][j] : 0.0f;
+            }
             if (h_aligned && n + 4 <= ldh) {
                 *reinterpret_cast<f32x4 *>(dst) = acc[mt][nt];
             } else {
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
 template <int KS, int NTW, int MT>
 __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     int n_rows, int M, int P, int col_groups, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt,
-    int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned)
+    int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu)
 {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -267,7 +274,10 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
                     const int n = n_base + q * 32 + 8 * lq;          // column_of(2q, 4 lq) .. column_of(2q+1, 4 lq + 3)
                     f16x8 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { o[j] = (f16)acc[mt][2 * q][j]; o[4 + j] = (f16)acc[mt][2 * q + 1][j]; }
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = relu_f16((f16)acc[mt][2 * q][j], relu);
+                        o[4 + j] = relu_f16((f16)acc[mt][2 * q + 1][j], relu);
+                    }
                     f16 *dst = H + m * ldh + n;
                     if (h_aligned && n + 8 <= ldh && (ldh % 8 == 0) && ((uintptr_t)H % 16 == 0)) {
                         *reinterpret_cast<f16x8 *>(dst) = o;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
                     const int n = n_base + nt * 16 + 4 * lq;
                     f16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)acc[mt][nt][j];
+                    for (int j = 0; j < 4; ++j) o[j] = relu_f16((f16)acc[mt][nt][j], relu);
                     f16 *dst = H + m * ldh + n;
                     if (h_aligned && n + 4 <= ldh) {
                         *reinterpret_cast<f16x4 *>(dst) = o;
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
 
 template <int KS, int NTW>
 int launch_stationary(int n_rows, int M, int P, int nt_total, const void *X, int64_t ldx, const void *Wt, int64_t ldw,
-                      void *H, int64_t ldh, int ha, hipStream_t s)
+                      void *H, int64_t ldh, int ha, hipStream_t s, int relu)
 {
     constexpr int MT = 2;
     const int groups = (nt_total + NTW - 1) / NTW;
@@ -311,14 +321,14 @@ int launch_stationary(int n_rows, int M, int P, int nt_total, const void *X, int
     waves = (waves + groups - 1) / groups * groups;
     const unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
     hipLaunchKernelGGL((xw_dense_stationary_f16_kernel<KS, NTW, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
-                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha);
+                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, relu);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
 
 // picks (KS, NTW) for the stationary kernel; SGX_ERR_UNSUPPORTED = use the tiled kernel
 int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H,
-                   int64_t ldh, int ha, hipStream_t s)
+                   int64_t ldh, int ha, hipStream_t s, int relu)
 {
     // measured (tools/bench_configs.py): 100 -> 256 on 2.4 M rows 1.31 -> 0.66 ms; with K > 128 the W
     // fragments leave room for one column tile only and the re-reads of X cost more than they save
@@ -326,7 +336,7 @@ int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const v
     if (M > 128 || n_rows < 8192) return SGX_ERR_UNSUPPORTED;
     const int nt_total = (int)((ldh + 15) / 16);               // pad columns P..ldh-1 are produced (as zeros) too
     const int ks = (M + 31) / 32;
-#define SGX_ST(KS_, NTW_) return launch_stationary<KS_, NTW_>(n_rows, M, P, nt_total, X, ldx, Wt, ldw, H, ldh, ha, s)
+#define SGX_ST(KS_, NTW_) return launch_stationary<KS_, NTW_>(n_rows, M, P, nt_total, X, ldx, Wt, ldw, H, ldh, ha, s, relu)
     if (ks <= 2) { if (nt_total >= 8) SGX_ST(2, 8); if (nt_total >= 4) SGX_ST(2, 4); if (nt_total >= 2) SGX_ST(2, 2); SGX_ST(2, 1); }
     if (ks <= 4) { if (nt_total >= 4) SGX_ST(4, 4); if (nt_total >= 2) SGX_ST(4, 2); SGX_ST(4, 1); }
     SGX_ST(4, 1);
@@ -335,16 +345,16 @@ int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const v
 
 template <int NT, int MT>
 int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
-                int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep)
+                int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
 {
     const int64_t rows_per_block = (int64_t)MT * 16 * (kBlock / 64);
     const unsigned grid = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
     if (dtype == SGX_F16)
         hipLaunchKernelGGL((xw_dense_f16_kernel<NT, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, p_base,
-                           (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, xa, wa, ha);
+                           (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, xa, wa, ha, relu);
     else
         hipLaunchKernelGGL((xw_dense_f32_kernel<NT, MT>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, p_base,
-                           (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha, ep);
+                           (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha, ep, relu);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -359,7 +369,7 @@ extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows,
 }
 
 int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
-                    const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep)
+                    const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep, int relu)
 {
     if (ep.rq_ten_pow != 0.0f && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;      // the quantised layer is fp32
     if (n_rows < 0 || M_fea < 1 || P < 1 || ldx < M_fea || ldw < M_fea || ldh < P) return SGX_ERR_SHAPE;
@@ -367,6 +377,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     if (!X || !Wt || !H) return SGX_ERR_NULL;
     if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
     hipStream_t s = stream;
+    if (relu && acc_mode != SGX_ACC_F32) return SGX_ERR_UNSUPPORTED;                  // ReLU on the stores: fp32-accumulate kernels only
     if (acc_mode == SGX_ACC_REF_HALF) {
         // the reference's sequential half arithmetic (refhalf.hip)
         if (dtype != SGX_F16) return SGX_ERR_UNSUPPORTED;
@@ -379,7 +390,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     const int wa = ((uintptr_t)Wt % 16 == 0) && ((ldw * es) % 16 == 0);
     const int ha = ((uintptr_t)H % (4 * es) == 0) && ((ldh * es) % (4 * es) == 0);
     if (dtype == SGX_F16) {
-        const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s);
+        const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
     // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
@@ -387,11 +398,11 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);
         const int nt = (cols + 15) / 16;
         int rc;
-        if (nt <= 1)       rc = launch_tile<1, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
-        else if (nt <= 2)  rc = launch_tile<2, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
-        else if (nt <= 4)  rc = launch_tile<4, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
-        else if (nt <= 8)  rc = launch_tile<8, 2>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
-        else               rc = launch_tile<16, 1>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep);
+        if (nt <= 1)       rc = launch_tile<1, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
+        else if (nt <= 2)  rc = launch_tile<2, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
+        else if (nt <= 4)  rc = launch_tile<4, 4>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
+        else if (nt <= 8)  rc = launch_tile<8, 2>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
+        else               rc = launch_tile<16, 1>(dtype, n_rows, M_fea, P, p_base, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
         if (rc != SGX_OK) return rc;
     }
     return SGX_OK;

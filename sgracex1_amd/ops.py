@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import SGX_ACC_F32, SGX_ACC_REF_HALF, SGX_F16, SGX_F32, LayerDesc, check, lib
+from ._lib import (SGX_ACC_F32, SGX_ACC_REF_HALF, SGX_F16, SGX_F32, SGX_ORDER_AGGREGATE_FIRST, SGX_ORDER_REFERENCE,
+                   LayerDesc, check, lib)
 
 _DTYPES = {torch.float16: SGX_F16, torch.float32: SGX_F32}
 
@@ -276,6 +277,20 @@ def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_p
     return acc_out if partial_out else out
 
 
+def table_pitch(width, elem_size):
+    """Row pitch (elements) for a table the aggregation gathers from: 16-byte multiples, whole 128-byte lines
+    where that costs at most a third more bytes, powers of two below one line (sgx_ldh, csrc/sgx_internal.h)."""
+    row = (width * elem_size + 15) // 16 * 16
+    if row < 128:
+        pitch = 16
+        while pitch < row:
+            pitch *= 2
+    else:
+        lines = (row + 127) // 128 * 128
+        pitch = lines if 3 * lines <= 4 * row else row
+    return pitch // elem_size
+
+
 def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
     """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M]."""
     _dev2d(X, "X")
@@ -285,8 +300,7 @@ def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
         raise TypeError(f"X [n, M] and Wt [P, M] must share the element type and M (got {X.dtype} {tuple(X.shape)}, "
                         f"{Wt.dtype} {tuple(Wt.shape)})")
     P, M = Wt.shape
-    per16 = 8 if code == SGX_F16 else 4
-    ldh = (P + per16 - 1) // per16 * per16 if ldh is None else ldh
+    ldh = table_pitch(P, X.element_size()) if ldh is None else ldh
     H = torch.empty((X.shape[0], ldh), dtype=X.dtype, device=X.device)
     check(lib.sgx_xw_dense(code, acc_mode, spmm_block, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0),
                            _ptr(H), ldh, _stream()), "sgx_xw_dense")
@@ -306,7 +320,7 @@ def transpose(x, ldo=None):
 def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
                   acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None,
                   quant=None, adj_quantized=False, cache_quantized_adj=True, fea_threads=1, adj_threads=1,
-                  gat_heads=1):
+                  gat_heads=1, order="reference"):
     """One fused layer  D = act(A . (X . W))  through sgx_layer_forward.
 
     adj : Csr [N, M_adj];  fea : Csr [M_adj, M_fea] (gemm_mode 0) or dense tensor (gemm_mode 1);
@@ -316,12 +330,23 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     bitstream (fp32 tensors only); adj_quantized: adj.val already went through the quantiser;
     cache_quantized_adj: quantise the adjacency once per graph on the host side instead of inside
     every call (always done for GAT, whose mask decides how rows without a live edge are treated).
+    order: "reference" -- X.W first, as the reference's dataflow; "aggregate_first" -- D = act((A.X).W), which
+    gathers M_fea instead of P columns per edge (dense X, GCN aggregate, default arithmetic only); "auto" --
+    aggregate first where that is allowed and M_fea < P.
     """
     _dev(Wt, "Wt")
     code = dtype_code(Wt.dtype)
     P, M_fea = Wt.shape
     d = LayerDesc()
     gemm_mode = 0 if isinstance(fea, Csr) else 1
+    if order not in ("reference", "aggregate_first", "auto"):
+        raise ValueError(f"order must be 'reference', 'aggregate_first' or 'auto', not {order!r}")
+    can_swap = gemm_mode == 1 and gat_attention is None and quant is None and acc_mode == SGX_ACC_F32
+    if order == "aggregate_first" and not can_swap:
+        raise ValueError("aggregate_first needs dense features, the GCN aggregate and the default arithmetic "
+                         "(no GAT, no quantised layer, no SGX_ACC_REF_HALF)")
+    swap = order == "aggregate_first" or (order == "auto" and can_swap and M_fea < P)
+    d.order = SGX_ORDER_AGGREGATE_FIRST if swap else SGX_ORDER_REFERENCE
     d.gemm_mode, d.relu, d.gat_mode = gemm_mode, int(bool(relu)), int(gat_attention is not None)
     d.N_adj, d.M_adj, d.M_fea, d.P_w = adj.n_rows, adj.n_cols, M_fea, P
     d.bias_count, d.dtype, d.acc_mode, d.spmm_block = bias_count, code, acc_mode, spmm_block

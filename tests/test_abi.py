@@ -93,6 +93,19 @@ def test_argument_checks_need_no_gpu(L):
     assert L.lib.sgx_spmm_csr(0, 0, 1, 0, 4, 4, 8, None, None, None, None, 8, None, 8, None, None, 0, None) == -1
     assert L.lib.sgx_xw_dense(0, 0, 1, 4, 0, 8, None, 8, None, 8, None, 8, None) == -2
     assert L.lib.sgx_transpose(0, 4, 4, None, 4, None, 4, None) == -1
+    # aggregate-first order: dense X, GCN aggregate, default arithmetic only; its workspace holds Z = A.X [N_adj][M_fea]
+    d.order = 1
+    swapped = L.lib.sgx_layer_workspace_bytes(ctypes.byref(d))
+    assert 10 * 8 * 2 <= swapped <= need and swapped % 256 == 0
+    for field, bad in (("gemm_mode", 0), ("gat_mode", 1), ("acc_mode", 1)):
+        keep = getattr(d, field)
+        setattr(d, field, bad)
+        assert L.lib.sgx_layer_workspace_bytes(ctypes.byref(d)) == 0, field
+        assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3, field
+        setattr(d, field, keep)
+    d.order = 2
+    assert L.lib.sgx_layer_forward(ctypes.byref(d), None) == -3
+    d.order = 0
     # quantised layer: fp32 only, zero points of the CSR operands must be 0, bit widths bounded
     q = L.Quant()
     q.qbits, q.scale_fea, q.internal_bits = 8, 4, 16

@@ -60,3 +60,79 @@ def test_uniform_graph_keeps_natural_order():
     from sgracex1_amd import graphs
     A = graphs.uniform_graph(1 << 14, 400_000, seed=1)
     assert A.plan.natural_utilization > 0.7 and not A.plan.reordered and A.plan.long_rows == 0
+
+
+@pytest.mark.parametrize("dtype,width,pitch", [
+    (torch.float16, 100, 100),     # ogbn-products' F_in: 200-byte rows, 8-byte aligned
+    (torch.float16, 602, 602),     # Reddit's F_in: 1204-byte rows, 4-byte aligned, wider than one 64-slot pass
+    (torch.float16, 47, 50),       # a view: 47 columns used of 100-byte rows
+    (torch.float16, 6, 6),         # 12-byte rows: every 16-byte gather runs into the next row
+    (torch.float32, 7, 7),         # MUTAG's F_in in fp32: 28-byte rows
+    (torch.float32, 25, 25),
+    (torch.float16, 41, 41),       # rows on odd halves: one element per lane (no vector gathers)
+])
+def test_tables_with_dword_aligned_rows(oracle, dtype, width, pitch):
+    """Aggregation over tables whose rows start on a dword but not on 16 bytes (the input feature matrix of
+    the backward products, unpadded hidden widths): vector gathers at dword alignment, hub rows through the
+    split path, the last row of the table ending inside a gather -- against the oracle's fp32 sums, and
+    the same bits as a 16-byte-aligned copy of the same table."""
+    from sgracex1_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(width * 7 + pitch)
+    n = 3000
+    deg = torch.randint(0, 12, (n,), generator=g, device="cuda")
+    deg[5] = 9000                                            # split path (plan cuts at 64 below 2^20 edges)
+    deg[n - 1] = 700
+    row = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    col = torch.randint(0, n, (row.numel(),), generator=g, device="cuda")
+    col[-1] = n - 1                                          # the table's last row is gathered
+    key = torch.unique(row * n + col)
+    row, col = torch.div(key, n, rounding_mode="floor"), key % n
+    val = (torch.rand(key.numel(), generator=g, device="cuda") * 0.2 + 0.01).to(dtype)
+    A = ops.Csr.from_coo(row.to(torch.int32), col.to(torch.int32), val, n, n)
+    store = (torch.rand((n, pitch), generator=g, device="cuda") - 0.4).to(dtype)
+    H = store[:, :width]
+    assert H.stride(0) == pitch
+    got = ops.spmm(A, H, relu=True)
+    assert got.shape == (n, width)
+    csr = (A.rowptr.cpu().numpy(), A.col.cpu().numpy(), A.val.float().cpu().numpy())
+    want = oracle.spmm_f32(1, csr, H.float().cpu().numpy())
+    tol = dict(rtol=4e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, **tol)
+    # 16-byte aligned copy of the table (padded pitch): the same fp32 chains, the same bits
+    per16 = 8 if dtype == torch.float16 else 4
+    padded = torch.zeros((n, (width + per16 - 1) // per16 * per16 + per16), dtype=dtype, device="cuda")
+    padded[:, :width] = H
+    assert torch.equal(ops.spmm(A, padded, relu=True, n_feat=width), got)
+    # without the plan the hub rows are one chain each instead of 64-edge tasks: another fp32 summation order
+    np.testing.assert_allclose(ops.spmm(A, H, relu=True, use_plan=False).float().cpu().numpy(), want, **tol)
+
+
+@pytest.mark.parametrize("dtype,M_fea,P", [(torch.float16, 100, 256), (torch.float16, 200, 64), (torch.float16, 100, 47),
+                                           (torch.float32, 7, 64), (torch.float32, 130, 41)])
+def test_aggregate_first_order(dtype, M_fea, P):
+    """order = aggregate_first: D = act((A.X).W).  Bit-equal to its two stages run one by one (A.X rounded to the
+    storage type, then the dense product with the ReLU on the rounded result), inside the layer's tolerance of
+    the reference order, and selected by order="auto" exactly when M_fea < P."""
+    from sgracex1_amd import graphs, ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M_fea * 1000 + P)
+    n = 20_011
+    A = graphs.uniform_graph(n, 300_000, seed=M_fea + P, dtype=dtype)
+    X = (torch.rand((n, M_fea), generator=g, device="cuda") - 0.3).to(dtype)
+    Wt = ((torch.rand((P, M_fea), generator=g, device="cuda") * 2 - 1) / M_fea ** 0.5).to(dtype)
+    for relu in (False, True):
+        swapped = ops.layer_forward(A, X, Wt, relu=relu, order="aggregate_first")
+        Z = ops.spmm(A, X)
+        H = ops.xw_dense(Z, Wt)
+        staged = torch.where(H > 0, H, torch.zeros_like(H)) if relu else H
+        assert torch.equal(swapped, staged)
+        ref = ops.layer_forward(A, X, Wt, relu=relu)
+        tol = dict(rtol=1e-2, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-5)
+        assert torch.allclose(swapped.float(), ref.float(), **tol), float((swapped.float() - ref.float()).abs().max())
+        auto = ops.layer_forward(A, X, Wt, relu=relu, order="auto")
+        assert torch.equal(auto, swapped if M_fea < P else ref)
+    with pytest.raises(ValueError):
+        ops.layer_forward(A, X, Wt, order="aggregate_first", acc_mode=ops.SGX_ACC_REF_HALF)
+    with pytest.raises(ValueError):
+        ops.layer_forward(A, X, Wt, order="columns_first")

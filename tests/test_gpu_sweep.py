@@ -59,6 +59,14 @@ def test_layer_forward_random_case(oracle, dtype, seed):
         got = ops.layer_forward(A, X, torch.as_tensor(Wt, device=dev).to(dtype), relu=c["relu"])
         assert got.shape == (N, P)
         np.testing.assert_allclose(got.float().cpu().numpy(), want, err_msg=str(c), **tol)
+        if c["gemm_mode"] == 1:
+            # the same layer aggregated first, D = act((A.X).W): another association of the same sums
+            swapped = ops.layer_forward(A, X, torch.as_tensor(Wt, device=dev).to(dtype), relu=c["relu"], order="aggregate_first")
+            np.testing.assert_allclose(swapped.float().cpu().numpy(), want, err_msg="aggregate_first " + str(c), **tol)
+            assert not swapped[torch.as_tensor(np.diff(a_csr[0]) == 0, device=dev)].any()
+        else:
+            with pytest.raises(ValueError):
+                ops.layer_forward(A, X, torch.as_tensor(Wt, device=dev).to(dtype), relu=c["relu"], order="aggregate_first")
     else:
         att = rnd(rng.standard_normal(2 * P) * (0.5 / np.sqrt(P)))
         _, H = oracle.layer_f64(c["gemm_mode"], 0, a_csr, fea, Wt, N=N, M_adj=M_adj, h_round=2 if half else 1, return_h=True)
