@@ -225,7 +225,7 @@ def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu,
     else:
         work = dist.all_to_all_single(halo_table[:n_halo], packed, output_split_sizes=plan.recv_counts,
                                       input_split_sizes=plan.send_counts, group=group, async_op=True)
-    partial = backend.spmm_partial(adj_own, h_local if h_local.is_contiguous() else h_local.contiguous())
+    partial = backend.spmm_partial(adj_own, h_local)          # a view with padded rows is fine: the kernels take a row pitch
     if work is not None:
         work.wait()
     return backend.spmm_finish(adj_halo, halo_table, partial, relu)
