@@ -229,15 +229,31 @@ def csr_from_edge_index(edge_index, n_rows, n_cols=None, values=None, dtype=torc
     return Csr.from_coo(row[keep].to(torch.int32), col[keep].to(torch.int32), val[keep].to(dtype), n_rows, n_cols)
 
 
+def _gatherable(H, n_feat=None):
+    """The table as the aggregation wants it: rows that start on a dword take 16-byte gathers; a table whose
+    rows start on odd halves (47 fp16 columns, unpadded) would be gathered one element per lane, so it is
+    copied once into rows of table_pitch() elements -- N x P elements moved against E x P gathered."""
+    n_feat = H.shape[1] if n_feat is None else n_feat
+    if (H.stride(0) * H.element_size()) % 4 == 0 and H.data_ptr() % 4 == 0:
+        return H
+    if H.shape[0] * n_feat < (1 << 16):
+        return H
+    padded = torch.empty((H.shape[0], table_pitch(n_feat, H.element_size())), dtype=H.dtype, device=H.device)
+    padded[:, :n_feat] = H[:, :n_feat]
+    return padded
+
+
 def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_ACC_F32, spmm_block=1):
     """D = act(A @ H[:, :n_feat]) -- the aggregation stage alone (sgx_spmm_csr)."""
     _dev2d(H, "H")
+    n_feat = H.shape[1] if n_feat is None else n_feat
+    if acc_mode == SGX_ACC_F32:
+        H = _gatherable(H, n_feat)
     code = dtype_code(H.dtype)
     if adj.val.dtype != H.dtype:
         raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
     if H.shape[0] < adj.n_cols:
         raise ValueError(f"H has {H.shape[0]} rows, the adjacency refers to {adj.n_cols} columns")
-    n_feat = H.shape[1] if n_feat is None else n_feat
     out = _out(out, adj.n_rows, n_feat, H.dtype, H.device)
     plan = adj.plan if (use_plan and adj.wants_plan) else None
     sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, n_feat) if plan is not None else 0
@@ -253,12 +269,13 @@ def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_p
     """Two-pass aggregation (sgx_spmm_csr_acc): with partial_out the fp32 sums acc_in + A @ H are
     returned; otherwise D = act(acc_in + A @ H) in H's dtype."""
     _dev2d(H, "H")
+    n_feat = H.shape[1]
+    H = _gatherable(H)
     code = dtype_code(H.dtype)
     if adj.val.dtype != H.dtype:
         raise TypeError("adjacency values and H must share one element type (MM.h:129-139)")
     if H.shape[0] < adj.n_cols:
         raise ValueError(f"H has {H.shape[0]} rows, the adjacency refers to {adj.n_cols} columns")
-    n_feat = H.shape[1]
     if acc_in is not None:
         _dev(acc_in, "acc_in")
         if acc_in.dtype != torch.float32 or acc_in.shape != (adj.n_rows, n_feat):

@@ -69,7 +69,8 @@ def test_uniform_graph_keeps_natural_order():
     (torch.float16, 6, 6),         # 12-byte rows: every 16-byte gather runs into the next row
     (torch.float32, 7, 7),         # MUTAG's F_in in fp32: 28-byte rows
     (torch.float32, 25, 25),
-    (torch.float16, 41, 41),       # rows on odd halves: one element per lane (no vector gathers)
+    (torch.float16, 41, 41),       # rows on odd halves: ops copies the table into padded rows first
+    (torch.float16, 5, 5),         # ... unless it is tiny: one element per lane (no vector gathers)
 ])
 def test_tables_with_dword_aligned_rows(oracle, dtype, width, pitch):
     """Aggregation over tables whose rows start on a dword but not on 16 bytes (the input feature matrix of
