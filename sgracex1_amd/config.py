@@ -22,6 +22,9 @@ _FLAGS = {
                 "backward always runs on the device kernels"),
     "compute_attention": (0, "0 = GCN aggregate A.H, 1 = single-head GAT edge softmax (register gat_mode)"),
     "float_type": (_np.float32, "element type of the layer buffers; np.float16 selects the HALF build's type"),
+    "layer_order": ("reference", "'reference': every layer forms X.W first, as the FPGA dataflow does; 'auto': a layer with "
+                                 "dense features narrower than its output aggregates first, act((A.X).W) -- same sums, "
+                                 "other association (sgx_layer_desc.order); no flag of this name in the reference"),
     "hidden_channels": (16, "default hidden width of the demo models"),
     "head_count": (1, "accepted, unused (the reference marks it 'not in use' as well)"),
     # -- accepted, no effect on this path --------------------------------------------------------

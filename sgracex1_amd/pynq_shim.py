@@ -209,9 +209,12 @@ class IP:
                              f"{'CSR' if gemm_mode == 0 else 'dense'}")
         rm.N_adj, rm.M_adj, rm.M_fea, rm.P_w = adj.n_rows, adj.n_cols, Wt.shape[1], Wt.shape[0]
         gat = attention if int(rm.gat_mode) else None
+        from . import config
+        if config.layer_order not in ("reference", "auto"):
+            raise ValueError(f"config.layer_order must be 'reference' or 'auto', not {config.layer_order!r}")
         return ops.layer_forward(adj, fea, Wt, relu=int(rm.relu), gat_attention=gat, alpha=self.alpha,
                                  want_edge_outputs=want_edge_outputs, bias_count=int(rm.bias_count), out=out,
-                                 quant=quant, adj_quantized=adj_quantized)
+                                 quant=quant, adj_quantized=adj_quantized, order=config.layer_order)
 
     # -- compat path: host buffers behind fake physical addresses ------------------------------
     def _start(self):

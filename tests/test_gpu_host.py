@@ -325,3 +325,32 @@ def test_stream_copy_moves_every_byte():
     assert lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), 0, stream) == 0
     assert lib.sgx_stream_copy(dst.data_ptr(), src.data_ptr(), 24, stream) != 0
     assert lib.sgx_stream_copy(dst.data_ptr() + 4, src.data_ptr(), 32, stream) != 0
+
+
+def test_config_layer_order_auto_reaches_the_modules():
+    """config.layer_order = 'auto': a dense layer narrower at its input than at its output (7 -> 64 on the MUTAG
+    batch, dense mode) aggregates first; same result within the layer's band, the flag back to 'reference'
+    restores the reference's dataflow bit for bit."""
+    import sgracex1_amd.config as config
+    from sgracex1_amd import molecule_gcn as M, pynq_shim
+    from sgracex1_amd.pyg_lite import to_dense_adj
+    dev = torch.device("cuda")
+    batch, _ = _mutag_batch(dev)
+    adj = to_dense_adj(batch.edge_index, batch.num_nodes)[0]
+    ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
+    torch.manual_seed(3)
+    layer = M.GraphConvolution_pynq(7, 64, ip).to(dev)
+    x = (batch.x + 0.25 * torch.rand_like(batch.x)).detach()                  # dense mode wants a dense X
+    assert config.layer_order == "reference"
+    base = layer(1, 1, 1, x, adj).detach()
+    try:
+        config.layer_order = "auto"
+        swapped = layer(1, 1, 1, x, adj).detach()
+        config.layer_order = "columns_first"
+        with pytest.raises(ValueError):
+            layer(1, 1, 1, x, adj)
+    finally:
+        config.layer_order = "reference"
+    assert torch.equal(layer(1, 1, 1, x, adj).detach(), base)
+    assert not torch.equal(swapped, base)                                     # another association: other roundings
+    np.testing.assert_allclose(swapped.float().cpu().numpy(), base.float().cpu().numpy(), rtol=1e-2, atol=2e-3)
