@@ -241,6 +241,13 @@ int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea,
                  const void *X, int64_t ldx, const void *Wt, int64_t ldw,
                  void *H, int64_t ldh, void *stream);
 
+/* The same product with the activation on its stores, D = act(X.Wt^T): the second stage of
+ * SGX_ORDER_AGGREGATE_FIRST (X := A.X) for callers that run the stages themselves (the multi-GPU exchange of
+ * sgracex1_amd/dist.py).  fp32-accumulate arithmetic only; pad columns P..ldh-1 are zeroed. */
+int sgx_xw_dense_act(int dtype, int relu, int n_rows, int M_fea, int P,
+                     const void *X, int64_t ldx, const void *Wt, int64_t ldw,
+                     void *H, int64_t ldh, void *stream);
+
 /* X.W with CSR X = loop_fea / compute1 in gemm_mode 0 (K.cpp:1960-2078).
  * W_rowmajor is [M_fea][ldw] (use sgx_transpose to get it from B). */
 int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P,

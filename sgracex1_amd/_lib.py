@@ -28,7 +28,7 @@ SYMBOLS = [
     "sgx_spmm_csr", "sgx_spmm_csr_acc", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
     "sgx_gat_aggregate", "sgx_gat_scratch_bytes", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
     "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear", "sgx_gat_backward_edges",
-    "sgx_stream_copy", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
+    "sgx_stream_copy", "sgx_xw_dense_act", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_version", "sgx_status_string",
 ]
 
@@ -140,6 +140,8 @@ def _load():
     lib.sgx_xt_g_workspace_bytes.restype = sz
     lib.sgx_xt_g.argtypes = [c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp, sz, vp]
     lib.sgx_xt_g.restype = c_int
+    lib.sgx_xw_dense_act.argtypes = [c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp]
+    lib.sgx_xw_dense_act.restype = c_int
     lib.sgx_stream_copy.argtypes = [vp, vp, c_i64, vp]
     lib.sgx_stream_copy.restype = c_int
     lib.sgx_event_create.argtypes = [ctypes.POINTER(vp)]

@@ -368,6 +368,13 @@ extern "C" int sgx_xw_dense(int dtype, int acc_mode, int spmm_block, int n_rows,
                            sgx_no_epilogue());
 }
 
+extern "C" int sgx_xw_dense_act(int dtype, int relu, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
+                                const void *Wt, int64_t ldw, void *H, int64_t ldh, void *stream)
+{
+    return sgx_xw_dense_ep(dtype, SGX_ACC_F32, 1, n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, (hipStream_t)stream,
+                           sgx_no_epilogue(), relu ? 1 : 0);
+}
+
 int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                     const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep, int relu)
 {

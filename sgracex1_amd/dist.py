@@ -130,6 +130,7 @@ class Backend:
     spmm_partial: Optional[Callable] = None
     spmm_finish: Optional[Callable] = None
     gat: Optional[Callable] = None      # gat(adj_compact, table, attention, alpha, relu) -> D_local (edge softmax)
+    xw_act: Optional[Callable] = None   # xw_act(Z_local, Wt, relu) -> act(Z.W): second stage of the aggregate-first order
 
 
 def hip_backend():
@@ -145,13 +146,27 @@ def hip_backend():
                    spmm_partial=lambda adj, table: ops.spmm_acc(adj, table, partial_out=True),
                    spmm_finish=lambda adj, table, partial, relu: ops.spmm_acc(adj, table, relu=relu, acc_in=partial),
                    gat=lambda adj, table, att, alpha, relu: ops.gat_aggregate(adj, table, att, alpha=alpha, relu=relu,
-                                                                              fill_dead_rows=False))
+                                                                              fill_dead_rows=False),
+                   xw_act=lambda Z, Wt, relu: ops.xw_dense(Z, Wt, relu=relu))
 
 
-def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None):
+def _stages(backend: Backend, fea_local, Wt, relu, aggregate_first):
+    """(rows to exchange, relu of the aggregation, what follows the aggregation).  Reference order: the rows of
+    H = X.W travel and the aggregation applies the activation.  aggregate_first (dense X narrower than the output,
+    sgx_layer_desc.order): the rows of X travel -- M_fea instead of P columns over xGMI and per gathered edge --
+    and the weight product with the activation follows the aggregation."""
+    if not aggregate_first:
+        return backend.xw(fea_local, Wt), relu, lambda d: d
+    if backend.xw_act is None or not isinstance(fea_local, torch.Tensor):
+        raise ValueError("aggregate_first needs dense local features and a backend with xw_act")
+    return fea_local, False, lambda z: backend.xw_act(z, Wt, relu)
+
+
+def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None,
+                    aggregate_first=False):
     """adj_local: rows of this rank, GLOBAL column indices.  Returns D_local."""
     world = len(bounds) - 1
-    h_local = backend.xw(fea_local, Wt)
+    h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
     sizes = [bounds[g + 1] - bounds[g] for g in range(world)]
     P = h_local.shape[1]
     if h_global is None:
@@ -167,17 +182,19 @@ def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, gr
         all_gather_into(stage, padded, group=group)
         for g in range(world):
             h_global[bounds[g]:bounds[g + 1]] = stage[g * big:g * big + sizes[g]]
-    return backend.spmm(adj_local, h_global, relu)
+    return finish(backend.spmm(adj_local, h_global, relu))
 
 
 def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPlan, group=None, table=None,
-               attention=None, alpha=0.2):
+               attention=None, alpha=0.2, aggregate_first=False):
     """adj_compact: rows of this rank with column indices already remapped by build_halo_plan.
     attention: the GAT vector a [2P] -> the edge-softmax aggregate instead of A.H.  The softmax is
     row-local, so the same halo rows serve it: the scores Wh.a2 of the halo rows are recomputed from
     the received rows, own row r is row r of the compact table.  (Rows left without a live edge give
     0 here: the dense emulation's mean over ALL nodes would need one more reduction across ranks.)"""
-    h_local = backend.xw(fea_local, Wt)
+    if aggregate_first and attention is not None:
+        raise ValueError("the edge softmax needs Wh: no aggregate-first order for GAT")
+    h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
     P = h_local.shape[1]
     if table is None:
         table = torch.empty((plan.n_table, P), dtype=h_local.dtype, device=h_local.device)
@@ -186,7 +203,7 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
     if attention is not None:
         return backend.gat(adj_compact, table, attention, alpha, relu)
-    return backend.spmm(adj_compact, table, relu)
+    return finish(backend.spmm(adj_compact, table, relu))
 
 
 def split_own_halo(rowptr, col_compact, val, n_own):
@@ -207,12 +224,12 @@ def split_own_halo(rowptr, col_compact, val, n_own):
 
 
 def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu, plan: HaloPlan, group=None,
-                       halo_table=None):
+                       halo_table=None, aggregate_first=False):
     """The halo exchange hidden behind the aggregation of the own-partition edges: start the
     all-to-all of the halo rows, sum the own edges into fp32 partials meanwhile, wait, add the halo
     edges (the PIPO overlap of the reference, K.cpp:3651-3749, moved to the inter-GPU step).
     adj_own: columns = own row ids; adj_halo: columns = rows of the received halo table."""
-    h_local = backend.xw(fea_local, Wt)
+    h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
     P = h_local.shape[1]
     n_halo = sum(plan.recv_counts)
     if halo_table is None:
@@ -228,4 +245,4 @@ def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu,
     partial = backend.spmm_partial(adj_own, h_local)          # a view with padded rows is fine: the kernels take a row pitch
     if work is not None:
         work.wait()
-    return backend.spmm_finish(adj_halo, halo_table, partial, relu)
+    return finish(backend.spmm_finish(adj_halo, halo_table, partial, relu))

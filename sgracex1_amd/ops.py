@@ -308,8 +308,9 @@ def table_pitch(width, elem_size):
     return pitch // elem_size
 
 
-def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
-    """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M]."""
+def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1, relu=False):
+    """H = X @ Wt.T on the matrix cores (sgx_xw_dense).  Wt = weights transposed, [P, M].
+    relu: the activation on the stores (sgx_xw_dense_act; the second stage of the aggregate-first order)."""
     _dev2d(X, "X")
     _dev2d(Wt, "Wt")
     code = dtype_code(X.dtype)
@@ -319,6 +320,12 @@ def xw_dense(X, Wt, ldh=None, acc_mode=SGX_ACC_F32, spmm_block=1):
     P, M = Wt.shape
     ldh = table_pitch(P, X.element_size()) if ldh is None else ldh
     H = torch.empty((X.shape[0], ldh), dtype=X.dtype, device=X.device)
+    if relu:
+        if acc_mode != SGX_ACC_F32:
+            raise ValueError("the activation rides on the fp32-accumulate kernels only")
+        check(lib.sgx_xw_dense_act(code, 1, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0), _ptr(H), ldh,
+                                   _stream()), "sgx_xw_dense_act")
+        return H[:, :P]
     check(lib.sgx_xw_dense(code, acc_mode, spmm_block, X.shape[0], M, P, _ptr(X), X.stride(0), _ptr(Wt), Wt.stride(0),
                            _ptr(H), ldh, _stream()), "sgx_xw_dense")
     return H[:, :P]

@@ -75,7 +75,11 @@ def _worker(rank, world, port, tmp, balance_nnz):
             out = a @ table
             return torch.clamp(out, min=0) if relu else out
 
-        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish, gat=gat)
+        def xw_act(z, Wt_, relu):
+            out = z @ Wt_.t()
+            return torch.clamp(out, min=0) if relu else out
+
+        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish, gat=gat, xw_act=xw_act)
         trp, tci, tva = torch.as_tensor(rp), torch.as_tensor(ci), torch.as_tensor(va)
         bounds = D.row_partition(n, world, trp if balance_nnz else None)
         assert bounds[0] == 0 and bounds[-1] == n and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
@@ -115,6 +119,18 @@ def _worker(rank, world, port, tmp, balance_nnz):
         d3 = D.layer_halo_overlap(backend, LocalCsr(*own, plan.n_own), LocalCsr(*halo, sum(plan.recv_counts)), Xl, Wt,
                                   True, plan)
         np.testing.assert_allclose(d3.numpy(), want[lo:hi], rtol=1e-5, atol=1e-5)
+        # aggregate-first order: the rows of X travel instead of the rows of H; act((A.X).W) on every exchange
+        for d_swapped in (
+                D.layer_allgather(backend, LocalCsr(lrp, lci, lva, n), Xl, Wt, True, bounds, aggregate_first=True),
+                D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan,
+                             aggregate_first=True),
+                D.layer_halo_overlap(backend, LocalCsr(*own, plan.n_own), LocalCsr(*halo, sum(plan.recv_counts)), Xl, Wt,
+                                     True, plan, aggregate_first=True)):
+            assert d_swapped.shape == (hi - lo, p)
+            np.testing.assert_allclose(d_swapped.numpy(), want[lo:hi], rtol=1e-4, atol=1e-4)
+        with pytest.raises(ValueError):
+            D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan,
+                         attention=torch.zeros(2 * p), aggregate_first=True)
         # GAT over the same halo rows against the single-process dense formula
         att = torch.as_tensor(rng.standard_normal(2 * p).astype(np.float32)) * 0.3
         H_all = H_full

@@ -47,6 +47,15 @@ def _worker(rank, world, port, tmp):
         # two passes sum the same terms in another order: equal to fp32 rounding, not bitwise
         assert torch.allclose(d3.float(), want[lo:hi].float(), rtol=2e-3, atol=2e-3)
         assert (d3 == want[lo:hi]).float().mean() > 0.98
+        # aggregate-first order over the same exchanges: the rows of X travel, act((A.X).W) follows
+        want_sw = ops.layer_forward(A, X, Wt, relu=True, order="aggregate_first")
+        s1 = D.layer_allgather(backend, ops.Csr(rp, ci, va, n), X[lo:hi].contiguous(), Wt, True, bounds, aggregate_first=True)
+        s2 = D.layer_halo(backend, ops.Csr(rp, plan.col_compact, va, plan.n_table), X[lo:hi].contiguous(), Wt, True, plan,
+                          aggregate_first=True)
+        assert torch.equal(s1, want_sw[lo:hi]) and torch.equal(s2, want_sw[lo:hi])
+        s3 = D.layer_halo_overlap(backend, ops.Csr(*own, plan.n_own), ops.Csr(*far, max(1, sum(plan.recv_counts))),
+                                  X[lo:hi].contiguous(), Wt, True, plan, aggregate_first=True)
+        assert torch.allclose(s3.float(), want_sw[lo:hi].float(), rtol=2e-3, atol=2e-3)
         # GAT shards the same way (row-local softmax): own row r is row r of the compact table
         att = ((torch.rand(2 * p, generator=g, device=dev) - 0.5) / 2).half()
         want_gat = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att)
