@@ -326,6 +326,37 @@ def main():
     else:
         total_nnz = nnz
 
+    # N > 1: the exchange on its own, outside the timed region (exchange time and bytes per link) -- the
+    # same collective on the same row lists, 5 rounds between barriers, slowest rank
+    exchange_stats = None
+    if world > 1:
+        row_bytes = hidden * 2
+        if halo is not None:
+            recv_rows, link_rows = sum(halo.recv_counts), max(max(halo.recv_counts), max(halo.send_counts))
+            dest = halo_table[:recv_rows] if overlap else table[halo.n_own:]
+
+            def exchange_once():
+                packed = D1.index_select(0, halo.send_rows) if halo.send_rows.numel() else D1.new_empty((0, hidden))
+                sdist.all_to_all_rows(dest, packed, halo.recv_counts, halo.send_counts)
+        else:
+            recv_rows, link_rows = n * (world - 1), n
+
+            def exchange_once():
+                sdist.all_gather_into(table, D1)
+        exchange_once()
+        barrier()
+        x0 = time.perf_counter()
+        for _ in range(5):
+            exchange_once()
+        barrier()
+        xt = torch.tensor([(time.perf_counter() - x0) / 5], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+        x_ms = float(xt.item()) * 1e3
+        exchange_stats = {"rows_received_per_rank_per_layer": recv_rows, "bytes_received_per_rank_per_layer": recv_rows * row_bytes,
+                          "max_bytes_per_link_per_layer": link_rows * row_bytes, "ms_alone_per_layer": x_ms,
+                          "GBps_busiest_link_alone": link_rows * row_bytes / (x_ms * 1e-3) / 1e9,
+                          "note": "pack + collective without any aggregation beside it, rank 0's lists, slowest rank's time"}
+
     # dominant kernel: the A.H aggregation (spmm_kernel), timed by events the launch path
     # recorded on its own stream inside the timed region
     agg_ms = sorted(b.elapsed_ms(e) for b, e in ev)
@@ -395,6 +426,8 @@ def main():
                      "agg_edges_per_s": agg_nnz / (agg_avg_ms * 1e-3),
                      "stream_copy_GBps_this_device": copy_gbps},
     }
+    if exchange_stats is not None:
+        line["exchange"] = exchange_stats
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)
     elif rank == 0:

@@ -91,6 +91,11 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert expect in rec["config"]["exchange"]
+    # the exchange on its own (outside the timed region): rows, bytes per link, time
+    x = rec["exchange"]
+    assert x["ms_alone_per_layer"] > 0 and x["rows_received_per_rank_per_layer"] > 0
+    assert x["bytes_received_per_rank_per_layer"] == x["rows_received_per_rank_per_layer"] * rec["config"]["hidden"] * 2
+    assert 0 < x["max_bytes_per_link_per_layer"] <= x["bytes_received_per_rank_per_layer"] * 2
 
 
 def test_bench_falls_back_to_the_one_pass_halo_exchange():
