@@ -118,7 +118,7 @@ def test_aggregate_first_order(dtype, M_fea, P):
     from sgracex1_amd import graphs, ops
     g = torch.Generator(device="cuda")
     g.manual_seed(M_fea * 1000 + P)
-    n = 20_011
+    n = 50_021 if M_fea == 100 else 20_011          # 100 columns x 50 K rows: the layer first copies X onto whole lines
     A = graphs.uniform_graph(n, 300_000, seed=M_fea + P, dtype=dtype)
     X = (torch.rand((n, M_fea), generator=g, device="cuda") - 0.3).to(dtype)
     Wt = ((torch.rand((P, M_fea), generator=g, device="cuda") * 2 - 1) / M_fea ** 0.5).to(dtype)
@@ -137,3 +137,27 @@ def test_aggregate_first_order(dtype, M_fea, P):
         ops.layer_forward(A, X, Wt, order="aggregate_first", acc_mode=ops.SGX_ACC_REF_HALF)
     with pytest.raises(ValueError):
         ops.layer_forward(A, X, Wt, order="columns_first")
+
+
+def test_large_table_with_straddling_rows_is_repitched():
+    """ops.spmm copies a large table of 200-byte rows onto whole 128-byte lines before a dense enough aggregation
+    (32 edges per table row and more); the sums are the same chains, so the bits equal those of the table as given."""
+    import ctypes
+    from sgracex1_amd import graphs, ops
+    from sgracex1_amd._lib import check, lib
+    n, P = 50_000, 100
+    A = graphs.uniform_graph(n, 2_000_000, seed=11)
+    assert A.nnz >= 32 * n
+    g = torch.Generator(device="cuda")
+    g.manual_seed(12)
+    X = (torch.rand((n, P), generator=g, device="cuda") - 0.5).half()
+    assert ops._gatherable(X, P, A.nnz).stride(0) == 128 and ops._gatherable(X, P, 8 * n) is X
+    got = ops.spmm(A, X, relu=True)
+    raw = torch.empty((n, P), dtype=torch.float16, device="cuda")
+    plan = A.plan
+    sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, P)
+    scratch = torch.empty(max(1, sbytes), dtype=torch.uint8, device="cuda")
+    check(lib.sgx_spmm_csr(0, 0, 1, 1, n, n, P, A.rowptr.data_ptr(), A.col.data_ptr(), A.val.data_ptr(), X.data_ptr(), P,
+                           raw.data_ptr(), P, plan.handle, scratch.data_ptr(), sbytes,
+                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "sgx_spmm_csr")
+    assert torch.equal(got, raw)
