@@ -143,8 +143,8 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         int64_t ld_table = d->M_fea;
         if (c.w_bytes) {
             const size_t es = sgx_elem_size(d->dtype);
-            SGX_HIP_CHECK(hipMemcpy2DAsync(W, (size_t)ldz * es, d->values_fea, (size_t)d->M_fea * es, (size_t)d->M_fea * es,
-                                           (size_t)d->M_adj, hipMemcpyDeviceToDevice, s));
+            rc = sgx_repitch_rows(d->values_fea, (int64_t)d->M_fea * es, W, ldz * (int64_t)es, (int)(d->M_fea * es), d->M_adj, s);
+            if (rc != SGX_OK) return rc;
             table = W;
             ld_table = ldz;
         }

@@ -100,6 +100,9 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     bool fea_stage = false, int ref_threads = 1, sgx_epilogue ep = sgx_no_epilogue());
 
 // sgx_xw_dense / sgx_gat_aggregate with the quantised layer's epilogue (the public entry points pass none)
+// rows copied from one pitch to another (util_kernels.hip); dst 16-byte aligned with a pitch that is a multiple of 16
+int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch, int row_bytes, int64_t n_rows,
+                     hipStream_t stream);
 int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                     const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep, int relu = 0);
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,

@@ -84,6 +84,33 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const u32x4 *__rest
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+// rows of row_bytes bytes from pitch src_pitch to pitch dst_pitch (a multiple of 16, dst 16-byte aligned): one lane per
+// 16-byte chunk of a destination row; the source needs element alignment only (under-aligned vector load), the bytes
+// of a row's last chunk beyond row_bytes are written as zero
+typedef u32x4 u32x4_u __attribute__((aligned(2)));
+__global__ __launch_bounds__(kBlock) void repitch_rows_kernel(const char *__restrict__ src, int64_t src_pitch,
+                                                              char *__restrict__ dst, int64_t dst_pitch, int row_bytes,
+                                                              int64_t n_rows)
+{
+    const int chunks = (row_bytes + 15) / 16;
+    const int64_t total = n_rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / chunks;
+        const int k = (int)(i - r * chunks);
+        const char *from = src + r * src_pitch + 16 * k;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (16 * k + 16 <= row_bytes) {
+            v = *reinterpret_cast<const u32x4_u *>(from);
+        } else {
+            union { u32x4 v; unsigned short h[8]; } u;
+            u.v = v;
+            for (int b = 0; 16 * k + 2 * b < row_bytes; ++b) u.h[b] = *reinterpret_cast<const unsigned short *>(from + 2 * b);
+            v = u.v;
+        }
+        *reinterpret_cast<u32x4 *>(dst + r * dst_pitch + 16 * k) = v;
+    }
+}
+
 int grid_1d(int64_t n)
 {
     int64_t b = (n + kBlock - 1) / kBlock;
@@ -143,6 +170,21 @@ extern "C" int sgx_coo_to_csr(const int32_t *rowIndex, int64_t nnz, int n_rows, 
     if (nnz < 0 || n_rows < 0) return SGX_ERR_SHAPE;
     hipLaunchKernelGGL(coo_to_csr_kernel, dim3(grid_1d(nnz + 1)), dim3(kBlock), 0, (hipStream_t)stream, rowIndex, nnz,
                        n_rows, rowPtr);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch, int row_bytes, int64_t n_rows,
+                     hipStream_t stream)
+{
+    if (n_rows <= 0 || row_bytes <= 0) return SGX_OK;
+    if (row_bytes % 2 != 0 || dst_pitch % 16 != 0 || (uintptr_t)dst % 16 != 0 || dst_pitch < (row_bytes + 15) / 16 * 16)
+        return SGX_ERR_ALIGN;
+    const int64_t total = n_rows * ((row_bytes + 15) / 16);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(repitch_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, (const char *)src, src_pitch,
+                       (char *)dst, dst_pitch, row_bytes, n_rows);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }

@@ -110,7 +110,7 @@ def test_tables_with_dword_aligned_rows(oracle, dtype, width, pitch):
 
 
 @pytest.mark.parametrize("dtype,M_fea,P", [(torch.float16, 100, 256), (torch.float16, 200, 64), (torch.float16, 100, 47),
-                                           (torch.float32, 7, 64), (torch.float32, 130, 41)])
+                                           (torch.float16, 101, 128), (torch.float32, 7, 64), (torch.float32, 130, 41)])
 def test_aggregate_first_order(dtype, M_fea, P):
     """order = aggregate_first: D = act((A.X).W).  Bit-equal to its two stages run one by one (A.X rounded to the
     storage type, then the dense product with the ReLU on the rounded result), inside the layer's tolerance of
@@ -118,7 +118,7 @@ def test_aggregate_first_order(dtype, M_fea, P):
     from sgracex1_amd import graphs, ops
     g = torch.Generator(device="cuda")
     g.manual_seed(M_fea * 1000 + P)
-    n = 50_021 if M_fea == 100 else 20_011          # 100 columns x 50 K rows: the layer first copies X onto whole lines
+    n = 50_021 if M_fea in (100, 101) else 20_011   # 100 columns x 50 K rows: the layer first copies X onto whole lines
     A = graphs.uniform_graph(n, 300_000, seed=M_fea + P, dtype=dtype)
     X = (torch.rand((n, M_fea), generator=g, device="cuda") - 0.3).to(dtype)
     Wt = ((torch.rand((P, M_fea), generator=g, device="cuda") * 2 - 1) / M_fea ** 0.5).to(dtype)
@@ -133,6 +133,15 @@ def test_aggregate_first_order(dtype, M_fea, P):
         assert torch.allclose(swapped.float(), ref.float(), **tol), float((swapped.float() - ref.float()).abs().max())
         auto = ops.layer_forward(A, X, Wt, relu=relu, order="auto")
         assert torch.equal(auto, swapped if M_fea < P else ref)
+    # captured into a hipGraph and replayed with new feature values: the same bits as the eager call
+    from sgracex1_amd.graphed import Graphed
+    out = torch.empty((n, P), dtype=dtype, device="cuda")
+    run = Graphed(lambda: ops.layer_forward(A, X, Wt, relu=True, order="aggregate_first", out=out))
+    X.mul_(-0.5)
+    out.zero_()
+    run()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ops.layer_forward(A, X, Wt, relu=True, order="aggregate_first"))
     with pytest.raises(ValueError):
         ops.layer_forward(A, X, Wt, order="aggregate_first", acc_mode=ops.SGX_ACC_REF_HALF)
     with pytest.raises(ValueError):
