@@ -123,6 +123,24 @@ def make_inputs(torch, graphs, ops, wl, rank, world, device, cut=1.0, boundary=1
     return A, X, W1t, W2t
 
 
+def cpu_port_aggregate(rowptr, col, val, H, threads):
+    """Part of the cpu_baseline leg (the only place outside tests/ and smoke() that runs the oracle): one A.H
+    pass of the oracle's C loops over numpy CSR arrays on `threads` threads; returns a callable for timing
+    (tools/cpu_paths.py puts it beside torch.sparse.mm and scipy)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    rows, hidden = rowptr.shape[0] - 1, H.shape[1]
+    out = np.zeros((rows, hidden), np.float32)
+    blocks = [(rows * t // threads, rows * (t + 1) // threads) for t in range(threads)]
+
+    def run():
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda b: O.spmm_f32_into(0, rowptr, col, val, H, out, b[0], b[1], hidden), blocks))
+    return run
+
+
 def cpu_baseline(torch, ops, A, X, W1t, W2t, frac):
     """The oracle's plain C loops on this box's host cores, on a bounded row sample of the
     same workload: rows [0, frac*N) of all four stages, full H tables (baseline only)."""
@@ -170,7 +188,7 @@ def cpu_baseline(torch, ops, A, X, W1t, W2t, frac):
     t += run(lambda lo, hi: O.spmm_f32_into(0, arp, aci, ava, H2, out, lo, hi, hidden))
     return {"value": 2.0 * ae / t, "unit": "edges/s", "cores": threads, "kind": "port",
             "sample": f"rows [0,{rows}) of both layers ({ae} edges per layer), all four stages, full H tables, "
-                      f"fp32, {t:.2f} s of CPU time on {threads} threads"}
+                      f"fp32, {t:.2f} s of wall time on {threads} threads"}
 
 
 def main():

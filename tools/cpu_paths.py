@@ -72,19 +72,10 @@ def main():
     print(json.dumps(dict(base, path="scipy.sparse.csr_matrix @ ndarray fp32", threads=1, seconds=t, edges_per_s=e / t)),
           flush=True)
 
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    O.lib()
-    out = np.zeros((rows, hidden), np.float32)
+    import bench                                  # its cpu_baseline leg owns the oracle port
     rpn, cin, van = rp.numpy(), ci.numpy(), va.numpy()
     for k in (1, min(cores, 32)):
-        blocks = [(rows * t_ // k, rows * (t_ + 1) // k) for t_ in range(k)]
-
-        def run():
-            with ThreadPoolExecutor(k) as ex:
-                list(ex.map(lambda b: O.spmm_f32_into(0, rpn, cin, van, Hn, out, b[0], b[1], hidden), blocks))
-
-        t = median_time(run, max(3, args.runs // 2))
+        t = median_time(bench.cpu_port_aggregate(rpn, cin, van, Hn, k), max(3, args.runs // 2))
         print(json.dumps(dict(base, path="oracle port (plain C loops, bench.py cpu_baseline kernel)", threads=k, seconds=t,
                               edges_per_s=e / t)), flush=True)
 
