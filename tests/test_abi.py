@@ -133,6 +133,13 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower(), (fn, "mentions the oracle")
                 assert "liborc" not in text
+    # examples/ and tools/ neither: the only importers outside tests/ are bench.py's cpu_baseline leg and
+    # __graft_entry__ (build of the checker, smoke's check)
+    for sub in ("examples", "tools"):
+        for fn in os.listdir(os.path.join(ROOT, sub)):
+            if fn.endswith((".py", ".cpp", ".sh")):
+                text = open(os.path.join(ROOT, sub, fn)).read()
+                assert "from oracle" not in text and "import oracle" not in text and "oracle/" not in text, fn
 
 
 def test_graft_entry_build_check_passes():
