@@ -213,9 +213,11 @@ int    sgx_layer_forward(const sgx_layer_desc *desc, void *stream);
 
 /* A.H aggregation = loop_adj / compute2 / writec (K.cpp:3339, :2483, :713):
  *   D[r][0:n_feat] = act( sum_e values[e] * H[columnIndex[e]][0:n_feat] ),  r in [0,n_rows)
- * H is [n_cols][ldh], D is [n_rows][ldd] (leading dimensions in elements).  For the 16-byte
- * gather path H must be 16-byte aligned with ldh*sizeof(elem) a multiple of 16; otherwise a
- * scalar path is taken.  scratch/scratch_bytes: needed only when `plan` has long rows
+ * H is [n_cols][ldh], D is [n_rows][ldd] (leading dimensions in elements).  Rows of H that start on
+ * a dword (H 4-byte aligned, ldh*sizeof(elem) a multiple of 4) are gathered 16 bytes per lane; rows on
+ * odd halves -- and, for tables of 4 GiB and more, rows that are not 16-byte aligned -- one element per
+ * lane.  Fastest when no row straddles a 128-byte line (ldh*sizeof(elem) a multiple of 128, or a power
+ * of two below it).  scratch/scratch_bytes: needed only when `plan` has long rows
  * (sgx_spmm_scratch_bytes). */
 int sgx_spmm_csr(int dtype, int acc_mode, int spmm_block, int relu,
                  int n_rows, int n_cols, int n_feat,
