@@ -160,3 +160,51 @@ def test_full_size_exact_mode_bits(workload, oracle):
     plain = ops.spmm(A, H, relu=True)[rows].cpu().numpy()
     assert (plain.view(np.uint16) != got.view(np.uint16)).mean() > 0.05
     assert np.abs(plain.astype(np.float32) - got.astype(np.float32)).max() < 4e-3
+
+
+def test_full_size_rmat_aggregation_properties(oracle):
+    """SURVEY 8d's second generator at full size (R-MAT, 4.2 M nodes, ~100 M edges): the plan cuts hub rows into
+    tasks and schedules the rest in degree order.  Sampled rows -- the hubs among them -- against the oracle, the
+    column-sum checksum, constant table -> row sums, and the scheduled result against the unscheduled kernel."""
+    import bench
+    from sgracex1_amd import graphs, ops
+    wl = bench.WORKLOADS["s100m-rmat"]
+    A, _X, _W1t, _W2t = bench.make_inputs(torch, graphs, ops, wl, 0, 1, dev)
+    del _X
+    torch.cuda.empty_cache()
+    n, P = A.n_rows, 64
+    plan = A.plan
+    assert plan.long_rows > 100 and plan.reordered
+    g = torch.Generator(device=dev)
+    g.manual_seed(21)
+    H = (torch.rand((n, P), generator=g, device=dev) - 0.25).half()
+    D = ops.spmm(A, H, relu=False)
+    assert torch.equal(ops.spmm(A, H, relu=False), D)                      # reproducible: no atomics on the split path
+    # sampled rows: 2048 random ones and the 64 longest
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    rows = torch.cat([torch.randint(0, n, (2048,), generator=g, device=dev), torch.topk(deg, 64).indices]).unique()
+    assert int(deg[rows].max()) > plan.long_threshold
+    srp, scol, sval, uniq = _sample_rows(A, rows)
+    want = oracle.spmm_f32(0, (srp, scol, sval), H[uniq].float().cpu().numpy())
+    got = D[rows].float().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4)
+    assert np.mean(got == want.astype(np.float16).astype(np.float32)) > 0.99
+    # checksum of checksums: column sums of D against edge-by-edge sums formed by torch
+    col_sum = torch.zeros(P, dtype=torch.float64, device=dev)
+    step = 8_000_000
+    for e0 in range(0, A.nnz, step):
+        e1 = min(A.nnz, e0 + step)
+        col_sum += (A.val[e0:e1].double()[:, None] * H[A.col[e0:e1].long()].double()).sum(0)
+    scale = D.double().abs().sum(0)
+    assert ((D.double().sum(0) - col_sum).abs() <= scale * 2.0 ** -11 * 0.02 + 1e-6).all()
+    # the schedule changes no sum of a short row; hub rows are summed in 4096-edge tasks: equal to fp32 rounding
+    plain = ops.spmm(A, H, relu=False, use_plan=False)
+    short = deg <= plan.long_threshold
+    assert torch.equal(plain[short], D[short])
+    assert torch.allclose(plain[~short].float(), D[~short].float(), rtol=2e-3, atol=2e-4)
+    # constant table -> row sums of A
+    ones = torch.ones((n, 8), dtype=torch.float16, device=dev)
+    rs = ops.spmm(A, ones, relu=False)
+    row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    want_rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, A.val.double())
+    assert (rs.double() - want_rs[:, None]).abs().max() <= 2.0 ** -10 * float(want_rs.max()) + 1e-3
