@@ -33,18 +33,7 @@ def workload():
     torch.cuda.empty_cache()
 
 
-def _sample_rows(A, rows):
-    """(rowptr, compact col, val, unique table rows) of the given rows of A, on the host."""
-    rp = A.rowptr
-    starts, ends = rp[rows].long(), rp[rows + 1].long()
-    deg = ends - starts
-    off = torch.repeat_interleave(starts - torch.cumsum(deg, 0) + deg, deg)
-    idx = off + torch.arange(int(deg.sum()), device=rp.device)
-    col, val = A.col[idx].long(), A.val[idx]
-    uniq, inv = torch.unique(col, return_inverse=True)
-    srp = torch.zeros(rows.numel() + 1, dtype=torch.int32)
-    srp[1:] = torch.cumsum(deg, 0).cpu().to(torch.int32)
-    return srp.numpy(), inv.cpu().numpy().astype(np.int32), val.float().cpu().numpy(), uniq
+from _fixtures import sample_rows as _sample_rows  # noqa: E402
 
 
 def test_full_size_aggregation_properties(workload, oracle):
