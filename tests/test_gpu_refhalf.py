@@ -126,3 +126,41 @@ def test_dense_stage_bit_exact_random(oracle, M, P, spmm_block, fea_threads):
     full = ops.layer_forward(A, _dev(x), _dev(wt), relu=0, acc_mode=ops.SGX_ACC_REF_HALF, spmm_block=spmm_block,
                              fea_threads=fea_threads)
     assert np.array_equal(full.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_reference_build_limits_exact_mode(oracle):
+    """The public build's maxima (MM.h:43-45: MAX_N = MAX_M = 6144, MAX_P = 128) in one call, sparse features,
+    SPMM_BLOCK 4, 2 FEA / 4 ADJ threads: the reference's half arithmetic bit for bit, and the default arithmetic
+    inside its band of the exact result."""
+    import torch
+    from sgracex1_amd import ops
+    rng = np.random.default_rng(6144)
+    N = M = 6144
+    P = 128
+
+    def csr(rows, cols, per_row, scale):
+        deg = rng.integers(0, 2 * per_row + 1, rows)
+        deg[7] = cols                                                      # one full row
+        deg[11] = 0
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum(deg)
+        ci = np.concatenate([np.sort(rng.choice(cols, d, replace=False)) for d in deg]).astype(np.int32)
+        va = ((rng.random(rp[-1]) - 0.3) * scale).astype(np.float16)
+        return rp, ci, va
+
+    a_csr, x_csr = csr(N, N, 12, 0.3), csr(N, M, 20, 1.0)
+    Wt = (rng.standard_normal((P, M)) * (0.7 / np.sqrt(40))).astype(np.float16)
+    kw = dict(spmm_block=4, fea_threads=2, adj_threads=4)
+    want = oracle.layer_refhalf(0, 1, a_csr, x_csr, Wt, N=N, M_adj=N, **kw)
+    dev = torch.device("cuda")
+
+    def up(c, n_cols):
+        return ops.Csr(torch.as_tensor(c[0], device=dev), torch.as_tensor(c[1], device=dev), torch.as_tensor(c[2], device=dev), n_cols)
+
+    A, X, W = up(a_csr, N), up(x_csr, M), torch.as_tensor(Wt, device=dev)
+    got = ops.layer_forward(A, X, W, relu=True, acc_mode=ops.SGX_ACC_REF_HALF, **kw)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    exact = oracle.layer_f64(0, 1, (a_csr[0], a_csr[1], a_csr[2].astype(np.float32)),
+                             (x_csr[0], x_csr[1], x_csr[2].astype(np.float32)), Wt.astype(np.float32), N=N, M_adj=N, h_round=2)
+    fast = ops.layer_forward(A, X, W, relu=True)
+    np.testing.assert_allclose(fast.float().cpu().numpy(), exact, rtol=1e-2, atol=3e-3)
