@@ -555,3 +555,25 @@ def test_sparse_features_with_very_short_rows(sgx, oracle, dtype, P):
     tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(got.float().cpu().numpy(), want, **tol)
     assert not got[torch.as_tensor(deg == 0, device="cuda")].any()
+
+
+@pytest.mark.parametrize("dtype,M,P", [(torch.float16, 300, 128), (torch.float16, 602, 256), (torch.float16, 256, 100),
+                                       (torch.float32, 300, 128), (torch.float32, 200, 250)])
+def test_xw_dense_tall_tiles(dtype, M, P):
+    """Dense X.W with K > 128 on enough rows for the taller MFMA tiles (32 768 rows and more), ragged at the end:
+    against the fp32 product of the same inputs, with and without the activation on the stores."""
+    from sgracex1_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + P)
+    n = 40_000 + 37
+    X = (torch.rand((n, M), generator=g, device="cuda") - 0.4).to(dtype)
+    Wt = ((torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5).to(dtype)
+    want = X.float() @ Wt.float().t()
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-5, atol=1e-5)
+    got = ops.xw_dense(X, Wt)
+    assert got.shape == (n, P) and torch.allclose(got.float(), want, **tol)
+    act = ops.xw_dense(X, Wt, relu=True)
+    assert torch.equal(act, torch.where(got > 0, got, torch.zeros_like(got)))
+    # pad columns of the scratch pitch are exact zeros (the aggregation's vector gathers may read them)
+    base = got._base if got._base is not None else got
+    assert not base[:, P:].any()
