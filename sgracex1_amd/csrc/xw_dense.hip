@@ -401,7 +401,8 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
     // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
-    const bool tall = n_rows >= 32768 && !getenv("SGX_XW_SHORT_TILES");
+    static const bool short_tiles = getenv("SGX_XW_SHORT_TILES") != nullptr;      // tuning override, read once
+    const bool tall = n_rows >= 32768 && !short_tiles;
     for (int p_base = 0; p_base < ldh; p_base += 256) {
         const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);
         const int nt = (cols + 15) / 16;
