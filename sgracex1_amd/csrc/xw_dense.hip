@@ -75,19 +75,29 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f16_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
 
-    for (int k0 = 0; k0 < M; k0 += 32) {
+    // the fragments of k-step s+1 are requested before the MFMAs of step s: without it every step waits out a full
+    // L2 / HBM round trip (602 -> 128 on 233 K rows: 0.190 ms with the loads inside the step)
+    f16x8 a[NT], b[MT], a_next[NT], b_next[MT];
+    auto fetch = [&](int k0, f16x8 *fa, f16x8 *fb) {
         const int k = k0 + 8 * lq;
-        f16x8 a[NT], b[MT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = p_base + nt * 16 + l15;
-            a[nt] = load_k8(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
+            fa[nt] = load_k8(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = row0 + mt * 16 + l15;
-            b[mt] = load_k8(X + m * ldx, k, M, m < n_rows, x_aligned);
+            fb[mt] = load_k8(X + m * ldx, k, M, m < n_rows, x_aligned);
         }
+    };
+    fetch(0, a_next, b_next);
+    for (int k0 = 0; k0 < M; k0 += 32) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[nt] = a_next[nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = b_next[mt];
+        if (k0 + 32 < M) fetch(k0 + 32, a_next, b_next);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -136,19 +146,27 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
 
-    for (int k0 = 0; k0 < M; k0 += 16) {
+    f32x4 a[NT], b[MT], a_next[NT], b_next[MT];
+    auto fetch = [&](int k0, f32x4 *fa, f32x4 *fb) {
         const int k = k0 + 4 * lq;
-        f32x4 a[NT], b[MT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = p_base + nt * 16 + l15;
-            a[nt] = load_k4(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
+            fa[nt] = load_k4(Wt + (int64_t)n * ldw, k, M, n < P, w_aligned);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = row0 + mt * 16 + l15;
-            b[mt] = load_k4(X + m * ldx, k, M, m < n_rows, x_aligned);
+            fb[mt] = load_k4(X + m * ldx, k, M, m < n_rows, x_aligned);
         }
+    };
+    fetch(0, a_next, b_next);
+    for (int k0 = 0; k0 < M; k0 += 16) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[nt] = a_next[nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) b[mt] = b_next[mt];
+        if (k0 + 16 < M) fetch(k0 + 16, a_next, b_next);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
