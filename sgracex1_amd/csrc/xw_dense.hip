@@ -326,6 +326,100 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Long K (fp16, M_fea > 128) on many rows: a workgroup computes 128 rows x 128 columns, its four wavefronts 64 x 64
+// each.  The k-steps' operand tiles (128 x 32 halves of X and of Wt) go through LDS, double buffered: the global
+// loads of step s+1 are in flight (16 bytes per lane, whole 64-byte row pieces per 4 lanes) while the MFMAs of step s
+// read their fragments from LDS, so W is fetched once per workgroup instead of once per wavefront and k-step, and
+// three workgroups per CU keep ~48 KB of X in flight.  Rows of 40 halves in LDS: the 16-byte fragment reads of 8
+// consecutive rows fall into 8 disjoint bank groups.
+// ---------------------------------------------------------------------------------------
+constexpr int kLdsBM = 128, kLdsBN = 128, kLdsBK = 32, kLdsPitch = kLdsBK + 8;
+
+__global__ __launch_bounds__(kBlock) void xw_dense_lds_f16_kernel(
+    int n_rows, int M, int P, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt, int64_t ldw,
+    f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu)
+{
+    __shared__ __attribute__((aligned(16))) f16 sX[2][kLdsBM * kLdsPitch];
+    __shared__ __attribute__((aligned(16))) f16 sW[2][kLdsBN * kLdsPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t row_base = (int64_t)blockIdx.x * kLdsBM;
+    const int col_base = blockIdx.y * kLdsBN;
+
+    // staging: a tile is 128 rows x 4 chunks of 16 bytes = 512 chunks, two per thread
+    f16x8 rx[2], rw[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + kBlock * i, r = c >> 2, k = k0 + 8 * (c & 3);
+            rx[i] = load_k8(X + (row_base + r) * ldx, k, M, row_base + r < n_rows, true);
+            rw[i] = load_k8(Wt + (int64_t)(col_base + r) * ldw, k, M, col_base + r < P, true);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + kBlock * i, r = c >> 2, part = c & 3;
+            *reinterpret_cast<f16x8 *>(&sX[buf][r * kLdsPitch + 8 * part]) = rx[i];
+            *reinterpret_cast<f16x8 *>(&sW[buf][r * kLdsPitch + 8 * part]) = rw[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+
+    // (two k-steps in flight in registers, the loop unrolled by two, was measured and lost: 206 VGPRs leave two
+    // workgroups per CU, 0.153 ms against 0.142 ms on 602 -> 128)
+    const int n_steps = (M + kLdsBK - 1) / kLdsBK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int s = 0; s < n_steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_steps) gload((s + 1) * kLdsBK);
+        f16x8 a[4], b[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            a[nt] = *reinterpret_cast<const f16x8 *>(&sW[buf][(64 * wc + nt * 16 + l15) * kLdsPitch + 8 * lq]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            b[mt] = *reinterpret_cast<const f16x8 *>(&sX[buf][(64 * wr + mt * 16 + l15) * kLdsPitch + 8 * lq]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[nt], b[mt], acc[mt][nt], 0, 0, 0);
+        if (s + 1 < n_steps) sstore(buf ^ 1);       // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int64_t m = row_base + 64 * wr + mt * 16 + l15;
+        if (m >= n_rows) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = col_base + 64 * wc + nt * 16 + 4 * lq;
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = relu_f16((f16)acc[mt][nt][j], relu);
+            f16 *dst = H + m * ldh + n;
+            if (h_aligned && n + 4 <= ldh) {
+                *reinterpret_cast<f16x4 *>(dst) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < ldh) dst[j] = o[j];
+            }
+        }
+    }
+}
+
 template <int KS, int NTW>
 int launch_stationary(int n_rows, int M, int P, int nt_total, const void *X, int64_t ldx, const void *Wt, int64_t ldw,
                       void *H, int64_t ldh, int ha, hipStream_t s, int relu)
@@ -418,9 +512,17 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
-    // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
     static const bool short_tiles = getenv("SGX_XW_SHORT_TILES") != nullptr;      // tuning override, read once
+    static const bool no_lds = getenv("SGX_XW_NO_LDS") != nullptr;
     const bool tall = n_rows >= 32768 && !short_tiles;
+    if (dtype == SGX_F16 && tall && !no_lds && M_fea > 128) {
+        const dim3 grid((unsigned)((n_rows + kLdsBM - 1) / kLdsBM), (unsigned)((ldh + kLdsBN - 1) / kLdsBN));
+        hipLaunchKernelGGL(xw_dense_lds_f16_kernel, grid, dim3(kBlock), 0, s, n_rows, M_fea, P, (const f16 *)X, ldx,
+                           (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, relu);
+        SGX_LAUNCH_CHECK();
+        return SGX_OK;
+    }
+    // columns are produced in blocks of up to 256 (16 tiles); the pad columns P..ldh-1 belong to the last block
     for (int p_base = 0; p_base < ldh; p_base += 256) {
         const int cols = (int)((ldh - p_base) < 256 ? (ldh - p_base) : 256);
         const int nt = (cols + 15) / 16;
