@@ -508,6 +508,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     const int xa = ((uintptr_t)X % 16 == 0) && ((ldx * es) % 16 == 0);
     const int wa = ((uintptr_t)Wt % 16 == 0) && ((ldw * es) % 16 == 0);
     const int ha = ((uintptr_t)H % (4 * es) == 0) && ((ldh * es) % (4 * es) == 0);
+    // (the LDS kernel below loses to this one on short K: 100 -> 256 on 2.4 M rows 0.78 vs 0.52 ms, 64 -> 64 0.29 vs 0.22 ms)
     if (dtype == SGX_F16) {
         const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;

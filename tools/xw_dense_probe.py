@@ -15,3 +15,9 @@ print(json.dumps({"ms_xw_602_256": timed(lambda: ops.xw_dense(X, W2), 50)}))
 G = torch.rand((2_449_029, 256), generator=gen, device="cuda").half()
 W3 = rand_w(100, 256, gen)
 print(json.dumps({"ms_xw_256_100_products_rows": timed(lambda: ops.xw_dense(G, W3), 20)}))
+X4 = torch.rand((2_449_029, 100), generator=gen, device="cuda").half()
+W4 = rand_w(256, 100, gen)
+print(json.dumps({"ms_xw_100_256_products_rows": timed(lambda: ops.xw_dense(X4, W4), 20)}))
+X5 = torch.rand((1 << 22, 64), generator=gen, device="cuda").half()
+W5 = rand_w(64, 64, gen)
+print(json.dumps({"ms_xw_64_64_s100m_rows": timed(lambda: ops.xw_dense(X5, W5), 20)}))
