@@ -577,3 +577,33 @@ def test_xw_dense_tall_tiles(dtype, M, P):
     # pad columns of the scratch pitch are exact zeros (the aggregation's vector gathers may read them)
     base = got._base if got._base is not None else got
     assert not base[:, P:].any()
+
+
+@pytest.mark.parametrize("dtype,F", [(torch.float16, 128), (torch.float16, 256), (torch.float16, 250), (torch.float32, 100),
+                                     (torch.float32, 256)])
+def test_gat_wide_rows_low_degree(oracle, dtype, F):
+    """Wide Wh rows over a low-degree graph (a piece of 16-32 edges is mostly empty), masked edges among the stored
+    ones: against the oracle (rows, E, S), and with / without the plan."""
+    from sgracex1_amd import graphs, ops
+    n = 6000
+    A = graphs.uniform_graph(n, 36_000, seed=F, dtype=dtype)               # ~7 edges per row with the self loops
+    assert A.wants_plan and 2 * A.nnz <= 16 * n
+    g = torch.Generator(device="cuda")
+    g.manual_seed(F)
+    Wh = (torch.randn((n, F), generator=g, device="cuda") * 0.5).to(dtype)
+    att = (torch.randn(2 * F, generator=g, device="cuda") * (0.5 / F ** 0.5)).to(dtype)
+    A.val[::7] = -A.val[::7].abs()                                          # stored but masked edges
+    got, E, S = ops.gat_aggregate(A, Wh, att, relu=True, want_edge_outputs=True)
+    csr = (A.rowptr.cpu().numpy(), A.col.cpu().numpy(), A.val.float().cpu().numpy())
+    want, wE, wS = oracle.gat_f64(1, csr, Wh.float().cpu().numpy(), att.float().cpu().numpy(), 0.2)
+    live = torch.zeros(n, dtype=torch.bool, device="cuda")
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    live[row[A.val > 0]] = True
+    lv = live.cpu().numpy()
+    tol = dict(rtol=1e-2, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got.float().cpu().numpy()[lv], want[lv], **tol)
+    np.testing.assert_allclose(S.cpu().numpy()[(lv[row.cpu().numpy()])], wS[lv[row.cpu().numpy()]], rtol=4e-3, atol=1e-5)
+    np.testing.assert_allclose(E.cpu().numpy(), wE, rtol=2e-3, atol=2e-3)
+    one_chunk = ops.gat_aggregate(A, Wh, att, relu=True, use_plan=False)
+    assert torch.allclose(got.float(), one_chunk.float(), rtol=2e-3 if dtype == torch.float16 else 1e-5, atol=1e-5)
