@@ -98,6 +98,19 @@ def main():
         "traffic_over_algorithmic": (read_bytes + write_bytes) / rl["algorithmic_bytes_per_launch"],
         "bench_line": bench_line,
     }
+    # the other stages of the step, raw counters per launch (the X.W kernels read narrow streams and an L2-resident
+    # table, or stream X once: no 16-byte-gather correction applied here)
+    fetch_all = load(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))
+    write_all = load(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))
+    others = {}
+    for label, sub in (("xw_sparse_kernel (X.W, CSR X, layer 1)", "xw_sparse_kernel"), ("xw_dense (X.W, dense X, layer 2)", "xw_dense")):
+        f_, w_ = counter(fetch_all, sub, "FETCH_SIZE"), counter(write_all, sub, "WRITE_SIZE")
+        h_, m_ = counter(l2, sub, "TCC_HIT_sum"), counter(l2, sub, "TCC_MISS_sum")
+        if f_:
+            others[label] = {"FETCH_SIZE_KB_per_launch": sum(f_) / len(f_), "WRITE_SIZE_KB_per_launch": sum(w_) / len(w_) if w_ else None,
+                             "TCC_HIT_per_launch": sum(h_) / len(h_) if h_ else None,
+                             "TCC_MISS_per_launch": sum(m_) / len(m_) if m_ else None}
+    summary["other_kernels_raw_counters"] = others
     with open(os.path.join(out, f"{tag}_{wl}_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(out, "traffic_latest.json"), "w") as f:
