@@ -170,3 +170,18 @@ template <int LPR, int TT> __device__ __forceinline__ float group_bcast(float x)
 {
     return __builtin_bit_cast(float, GroupBcast<LPR, TT>::run(__builtin_bit_cast(int, x)));
 }
+
+// what one fp32 sum becomes in D: the stage's epilogue (fp32 outputs of the quantised layer only), then ReLU
+template <typename T>
+__device__ __forceinline__ T finish_value(float sum, int relu, const sgx_epilogue &ep)
+{
+    if constexpr (sizeof(T) == 4) {
+        if (ep.rq_ten_pow != 0.0f) sum = sgx_requant_value(sum, ep);
+    }
+    T v = Elem<T>::from_f32(sum);
+    v = (!relu || v > (T)0) ? v : (T)0;                    // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
+    if constexpr (sizeof(T) == 4) {
+        if (ep.out_scale != 0.0f) v = v * ep.out_scale;
+    }
+    return v;
+}

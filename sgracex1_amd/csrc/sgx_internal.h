@@ -99,6 +99,12 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
                     const float *acc_in = nullptr, float *acc_out = nullptr, int64_t ld_acc = 0,
                     bool fea_stage = false, int ref_threads = 1, sgx_epilogue ep = sgx_no_epilogue());
 
+// X.W for a CSR X with the weight slice resident in LDS (xw_sparse_lds.hip); the caller checks _applicable first
+bool sgx_xw_sparse_lds_applicable(int dtype, int n_rows, int m_fea, int n_feat, int64_t ldh, const sgx_plan *plan);
+int sgx_xw_sparse_lds(int dtype, int n_rows, int m_fea, int n_feat, const int32_t *rowPtr, const int32_t *columnIndex,
+                      const void *values, const void *W, int64_t ldw, void *H, int64_t ldh, const sgx_plan *plan,
+                      sgx_epilogue ep, hipStream_t stream);
+
 // sgx_xw_dense / sgx_gat_aggregate with the quantised layer's epilogue (the public entry points pass none)
 // rows copied from one pitch to another (util_kernels.hip); dst 16-byte aligned with a pitch that is a multiple of 16
 int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch, int row_bytes, int64_t n_rows,

@@ -165,21 +165,6 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
     }
 }
 
-// what one fp32 sum becomes in D: the stage's epilogue (fp32 outputs of the quantised layer only), then ReLU
-template <typename T>
-__device__ __forceinline__ T finish_value(float sum, int relu, const sgx_epilogue &ep)
-{
-    if constexpr (sizeof(T) == 4) {
-        if (ep.rq_ten_pow != 0.0f) sum = sgx_requant_value(sum, ep);
-    }
-    T v = Elem<T>::from_f32(sum);
-    v = (!relu || v > (T)0) ? v : (T)0;                    // K.cpp:2586-2590: keep when (v > 0 || relu == 0), else +0
-    if constexpr (sizeof(T) == 4) {
-        if (ep.out_scale != 0.0f) v = v * ep.out_scale;
-    }
-    return v;
-}
-
 template <typename T, int VEC>
 __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_feat, const float *acc, int relu,
                                           bool vec_store, const sgx_epilogue &ep)
@@ -486,6 +471,9 @@ int sgx_spmm_launch(int dtype, int acc_mode, int spmm_block, int relu, int n_row
     const bool big = table_bytes > kOOBRow || (unsigned long long)n_feat * es > kMaxRowBytes;
     if ((unsigned long long)ldh * es >= 0xFFFFFFF0ull) return SGX_ERR_UNSUPPORTED;
     if (n_cols > 0 && (!H || !columnIndex || !values)) return SGX_ERR_NULL;
+    // X.W over a large CSR X: the weight slice resident in LDS instead of gathered through L2 (same sums, same order)
+    if (fea_stage && !acc_in && !acc_out && !big && sgx_xw_sparse_lds_applicable(dtype, n_rows, n_cols, n_feat, ldd, plan))
+        return sgx_xw_sparse_lds(dtype, n_rows, n_cols, n_feat, rowPtr, columnIndex, values, H, ldh, D, ldd, plan, ep, stream);
 
     LaunchArgs a;
     a.relu = relu; a.n_rows = n_rows; a.n_feat = n_feat;

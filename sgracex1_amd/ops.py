@@ -269,6 +269,26 @@ def spmm(adj, H, relu=False, n_feat=None, out=None, use_plan=True, acc_mode=SGX_
     return out
 
 
+def xw_sparse(X, W, out=None, use_plan=True):
+    """H = X @ W for a CSR X and a row-major W [M_fea, P] -- the X.W stage alone in gemm_mode 0 (sgx_xw_sparse):
+    the weight slice resident in LDS for a large X, gathered through L2 otherwise; same sums either way."""
+    _dev2d(W, "W")
+    if X.val.dtype != W.dtype:
+        raise TypeError("feature values and W must share one element type (MM.h:129-139)")
+    if W.shape[0] < X.n_cols:
+        raise ValueError(f"W has {W.shape[0]} rows, X refers to {X.n_cols} columns")
+    P = W.shape[1]
+    W = _gatherable(W, P, X.nnz)
+    out = _out(out, X.n_rows, P, W.dtype, W.device)
+    plan = X.plan if (use_plan and X.wants_plan) else None
+    sbytes = lib.sgx_spmm_scratch_bytes(plan.handle, P) if plan is not None else 0
+    scratch = _workspace(W.device, sbytes) if sbytes else None
+    check(lib.sgx_xw_sparse(dtype_code(W.dtype), SGX_ACC_F32, 1, X.n_rows, X.n_cols, P, _ptr(X.rowptr), _ptr(X.col),
+                            _ptr(X.val), _ptr(W), W.stride(0), _ptr(out), out.stride(0),
+                            plan.handle if plan is not None else None, _ptr(scratch), sbytes, _stream()), "sgx_xw_sparse")
+    return out
+
+
 def spmm_acc(adj, H, relu=False, acc_in=None, partial_out=False, out=None, use_plan=True):
     """Two-pass aggregation (sgx_spmm_csr_acc): with partial_out the fp32 sums acc_in + A @ H are
     returned; otherwise D = act(acc_in + A @ H) in H's dtype."""

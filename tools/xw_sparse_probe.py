@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Times the sparse X.W stage (sgx_xw_sparse = the X.W entry point of the aggregation body) on the
-bench workload's feature matrix with the lanes-per-row split forced (SGX_SPMM_CPL = 1, 2, 4)."""
+"""Times the sparse X.W stage (sgx_xw_sparse) on the bench workload's feature matrix: the LDS-resident weight
+slice against the gather kernel (SGX_XW_SPARSE_NO_LDS), and the gather kernel with the lanes-per-row split forced
+(SGX_SPMM_CPL = 1, 2, 4)."""
 import ctypes
 import json
 import os
@@ -45,6 +46,23 @@ def timed(iters=20):
 
 
 rec = {"rows": X.n_rows, "nnz": X.nnz, "f_in": X.n_cols, "P": W.shape[1]}
+if os.environ.get("SGX_PROBE_ONLY"):                    # under rocprofv3 --pmc: a few launches of one form
+    if os.environ["SGX_PROBE_ONLY"] == "gather":
+        os.environ["SGX_XW_SPARSE_NO_LDS"] = "1"
+    for _ in range(4):
+        run()
+    torch.cuda.synchronize()
+    print(json.dumps(rec), flush=True)
+    sys.exit(0)
+# the LDS-resident weight slice (default for a matrix this size) against the gather kernel, interleaved in one process
+for rnd in range(3):
+    rec.setdefault("ms_lds", []).append([round(v, 4) for v in timed()])
+    os.environ["SGX_XW_SPARSE_NO_LDS"] = "1"
+    rec.setdefault("ms_gather", []).append([round(v, 4) for v in timed()])
+    del os.environ["SGX_XW_SPARSE_NO_LDS"]
+run()
+H_lds = H.clone()
+os.environ["SGX_XW_SPARSE_NO_LDS"] = "1"
 for cpl in (1, 2, 4):
     os.environ["SGX_SPMM_CPL"] = str(cpl)
     rec[f"ms_cpl{cpl}"] = [round(v, 4) for v in timed()]
@@ -53,4 +71,6 @@ rec["ms_policy"] = [round(v, 4) for v in timed()]
 ref = ops.spmm(X, W, relu=False)              # the A.H entry point on the same operands: same sums, same bits
 run()
 rec["equal_to_agg_entry"] = bool(torch.equal(ref, H))
+rec["lds_equal_to_gather"] = bool(torch.equal(H_lds, H))
+del os.environ["SGX_XW_SPARSE_NO_LDS"]
 print(json.dumps(rec), flush=True)
