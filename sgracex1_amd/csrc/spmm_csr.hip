@@ -74,7 +74,9 @@ __device__ __forceinline__ void accumulate_edges(float *acc, int e0, int e1, int
     T a_next[PIECES];
     constexpr unsigned kNoEdge = 0xFFFFFFFFu;
     auto fetch = [&](int idx, unsigned &c, T &a) {
-        c = STYLE == 0 ? 0u : kNoEdge;
+        // a slot past the end of the row: the sentinel wherever a predicate reads it (STYLE 1, and every style on the
+        // 64-bit pointer path, which has no range check: column 0 would be loaded and 0 x inf = NaN)
+        c = (STYLE == 0 && !BIG) ? 0u : kNoEdge;
         a = (T)0;
         if (idx < e1) {
             c = (unsigned)__builtin_nontemporal_load(col + idx);                 // streamed once: keep L2 for H

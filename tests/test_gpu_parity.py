@@ -471,6 +471,11 @@ def test_spmm_table_beyond_4gib(sgx):
     assert torch.allclose(got, want, rtol=2e-3, atol=2e-3)
     assert torch.allclose(got[:, 1], torch.as_tensor(np.add.reduceat(np.append(va, 0), rp[:-1]) * (deg > 0),
                                                       device="cuda", dtype=torch.float32), rtol=2e-3, atol=2e-3)
+    # empty slots of a lane group (degrees 1..7 fill 1..7 of its 8 slots) must not touch row 0 of the table: with a
+    # non-finite H[0] every row that does not reference column 0 stays finite
+    H[0] = float("inf")
+    A1 = sgx.Csr(_dev(rp), _dev(np.maximum(ci, 1)), _dev(va, torch.float16), n_cols)
+    assert (deg % 8 != 0).any() and torch.isfinite(sgx.spmm(A1, H, relu=False, use_plan=False).float()).all()
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])

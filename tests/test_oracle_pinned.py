@@ -10,7 +10,7 @@ The reference C++ itself cannot be built in this image (Xilinx HLS headers absen
 import numpy as np
 import pytest
 
-from _fixtures import csr_to_dense, half_ulp_distance, known_answers, load
+from _fixtures import assert_prints_csim_log, csr_to_dense, half_ulp_distance, known_answers, load
 
 
 def _g(x):
@@ -31,23 +31,18 @@ def test_kat_4x4(oracle):
 
 
 def test_csim_log_citeseer(oracle):
-    """HALF build, SPMM_BLOCK=4, FADD latency 4: 40 of the 42 logged values are reproduced
-    to the printed digit, the other two (row 0 col 10, row 31 col 18) are one binary16 ulp
-    away.  Every other (SPMM_BLOCK, latency) setting reproduces at most 36."""
+    """HALF build, SPMM_BLOCK=4, FADD latency 4: 40 of the 42 logged values are reproduced to the printed digit; the
+    other two -- (row 0, col 10) and (row 31, col 18), exactly these, one binary16 ulp each, the model's magnitude above
+    the log's -- are printed by no setting or reading of the checked-in source (tools/csim_residual.py enumerates
+    them; profiles/r02_csim_residual.txt), so the log comes from a kernel revision that differs from the source there.
+    Every other (SPMM_BLOCK, latency, thread) setting reproduces fewer."""
     d = load("citeseer")
     ka = known_answers()["csim_log"]
     Wt = oracle.to_half(d["Wt"])
     D = oracle.layer_refhalf(0, 0, d["adj"], d["fea"], Wt, spmm_block=4, lat_fea=4, lat_adj=4)
-    exact, worst = 0, 0
-    for r in ("0", "31"):
-        assert len(ka[r]) == 21
-        for j, text in enumerate(ka[r]):
-            got = D[int(r), j]
-            if _g(got) == text:
-                exact += 1
-            worst = max(worst, int(half_ulp_distance(got, np.float16(float(text)))))
-    assert exact >= 40, exact
-    assert worst <= 1, worst
+    assert all(len(ka[r]) == 21 for r in ("0", "31"))
+    assert_prints_csim_log({(int(r), j): _g(D[int(r), j]) for r in ("0", "31") for j in range(21)})
+    exact = 40
     # the default build setting (SPMM_BLOCK=1) is a different, observable summation order
     D1 = oracle.layer_refhalf(0, 0, d["adj"], d["fea"], Wt, spmm_block=1)
     exact1 = sum(_g(D1[int(r), j]) == t for r in ("0", "31") for j, t in enumerate(ka[r]))
@@ -60,9 +55,11 @@ def test_hardware_row0(oracle):
     Wt = oracle.to_half(np.ascontiguousarray(d["Wt"][:16]))
     D = oracle.layer_refhalf(0, 0, d["adj"], d["fea"], Wt, spmm_block=4)
     shown = [np.format_float_positional(x, unique=True) for x in D[0]]
-    assert sum(a == b.rstrip("0") or a == b for a, b in zip(shown, hw)) >= 15
+    # the board printed the same (row 0, col 10) the csim log has: the one entry of this row the source does not give
+    assert [j for j, (a, b) in enumerate(zip(shown, hw)) if not (a == b.rstrip("0") or a == b)] == [10]
     want = np.array([float(t) for t in hw], dtype=np.float16)
     assert half_ulp_distance(D[0], want).max() <= 1
+    assert float(want[10]) == float(np.float16(float(known_answers()["csim_log"]["0"][10])))
 
 
 def test_scipy_row0(oracle):
