@@ -191,6 +191,67 @@ def cpu_baseline(torch, ops, A, X, W1t, W2t, frac):
                       f"fp32, {t:.2f} s of wall time on {threads} threads"}
 
 
+def cpu_reference_formulation(torch, ops, A, X, W1t, W2t, frac, budget_s=12.0):
+    """The reference's own CPU path for the same layers -- `support = torch.mm(input, weight)`, `output =
+    torch.spmm(adj, support)` (GNN_arc.pdf p.13 Listing 1.3; Graph_Classification.ipynb cell 17, acc == 0) -- in fp32
+    on this box's host cores: rows [0, frac N) of both layers against the full H tables, at one thread and at the
+    granted core count.  Baseline only; repetitions stop at `budget_s` seconds per thread setting."""
+    rows = max(64, int(A.n_rows * frac))
+    hidden = W1t.shape[0]
+    ae = int(A.rowptr[rows])
+    A_s = torch.sparse_csr_tensor(A.rowptr[:rows + 1].cpu().long(), A.col[:ae].cpu().long(), A.val[:ae].float().cpu(),
+                                  size=(rows, A.n_cols))
+    W1, W2 = W1t.float().cpu().t().contiguous(), W2t.float().cpu().t().contiguous()
+    if isinstance(X, ops.Csr):
+        xe = int(X.rowptr[rows])
+        X_s = torch.sparse_csr_tensor(X.rowptr[:rows + 1].cpu().long(), X.col[:xe].cpu().long(), X.val[:xe].float().cpu(),
+                                      size=(rows, X.n_cols))
+        H1 = ops.spmm(X, ops.transpose(W1t), relu=False, use_plan=False).float().cpu()
+    else:
+        X_s = X[:rows].float().cpu()
+        H1 = ops.xw_dense(X, W1t).contiguous().float().cpu()
+    D1 = ops.spmm(A, H1.to(W1t.device).half(), relu=True)
+    H2 = ops.xw_dense(D1, W2t).contiguous().float().cpu()
+    D1_s = D1[:rows].float().cpu()
+
+    def forward():
+        s1 = torch.sparse.mm(X_s, W1) if X_s.layout != torch.strided else torch.mm(X_s, W1)     # support of layer 1 (sample rows)
+        o1 = torch.relu(torch.sparse.mm(A_s, H1))
+        s2 = torch.mm(D1_s, W2)
+        o2 = torch.sparse.mm(A_s, H2)
+        return s1, o1, s2, o2
+
+    out = {"formulation": "torch.sparse.mm(adj_csr, support), support = torch.(sparse.)mm(input, weight), fp32 "
+                          "(GNN_arc.pdf Listing 1.3; Graph_Classification.ipynb cell 17, acc == 0)",
+           "sample": f"rows [0,{rows}) of both layers ({ae} edges per layer), all four products, full H tables"}
+    before = torch.get_num_threads()
+    granted = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for label, k in (("threads_1", 1), ("threads_granted", max(1, min(granted, 64)))):
+        torch.set_num_threads(k)
+        forward()                                                     # warm-up
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < 5 and (time.perf_counter() - t_all < budget_s or not ts):
+            t0 = time.perf_counter()
+            forward()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[label] = {"threads": k, "edges_per_s": 2.0 * ae / ts[len(ts) // 2], "runs": len(ts), "median_s": ts[len(ts) // 2]}
+    torch.set_num_threads(before)
+    return out
+
+
+def device_identity(torch, device):
+    """What tells one GPU of the node from another in the bench line: host, index, name, PCI bus / uuid where torch has them."""
+    import socket
+    p = torch.cuda.get_device_properties(device)
+    parts = [socket.gethostname(), f"cuda:{device.index}", p.name]
+    for attr in ("pci_bus_id", "pci_device_id", "uuid"):
+        v = getattr(p, attr, None)
+        if v is not None:
+            parts.append(f"{attr}={v}")
+    return " ".join(str(x) for x in parts)
+
+
 def main():
     args = parse()
     import torch
@@ -215,6 +276,17 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend_name)
+
+    # what the line must prove for N > 1: the backend that actually carried the exchange, the number of ranks IT sees,
+    # and one identity per rank (distinct devices = the ranks really sat on different GPUs)
+    dist_backend = dist.get_backend() if world > 1 else None
+    dist_world = dist.get_world_size() if world > 1 else 1
+    devices = [device_identity(torch, device)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+    coll = {"nccl": "RCCL"}.get(dist_backend, dist_backend)
 
     wl = WORKLOADS[args.workload]
     if args.cut >= 0.5:
@@ -320,10 +392,12 @@ def main():
             raise
         failed = 1
         print(f"[bench rank {rank}] overlapped halo exchange failed in warm-up: {exc!r}", file=sys.stderr, flush=True)
+    exchange_fallback = False
     if world > 1 and overlap:
         flag = torch.tensor([failed], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
+            exchange_fallback = True
             overlap, exchange, agg_nnz = False, "halo", nnz
             for _ in range(args.warmup):
                 step(0, False)
@@ -347,33 +421,54 @@ def main():
     # N > 1: the exchange on its own, outside the timed region (exchange time and bytes per link) -- the
     # same collective on the same row lists, 5 rounds between barriers, slowest rank
     exchange_stats = None
+    allgather_stats = None
     if world > 1:
         row_bytes = hidden * 2
+
+        def time_alone(fn, rounds=5):
+            fn()
+            barrier()
+            x0 = time.perf_counter()
+            for _ in range(rounds):
+                fn()
+            barrier()
+            xt = torch.tensor([(time.perf_counter() - x0) / rounds], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(xt, op=dist.ReduceOp.MAX)
+            return float(xt.item()) * 1e3
+
         if halo is not None:
             recv_rows, link_rows = sum(halo.recv_counts), max(max(halo.recv_counts), max(halo.send_counts))
             dest = halo_table[:recv_rows] if overlap else table[halo.n_own:]
 
             def exchange_once():
-                packed = D1.index_select(0, halo.send_rows) if halo.send_rows.numel() else D1.new_empty((0, hidden))
+                packed = (ops.pack_rows(D1, halo.send_rows32) if halo.send_rows.numel() else D1.new_empty((0, hidden)))
                 sdist.all_to_all_rows(dest, packed, halo.recv_counts, halo.send_counts)
+            what = f"HIP pack kernel + {coll} all-to-all of the halo rows"
         else:
             recv_rows, link_rows = n * (world - 1), n
 
             def exchange_once():
                 sdist.all_gather_into(table, D1)
-        exchange_once()
-        barrier()
-        x0 = time.perf_counter()
-        for _ in range(5):
-            exchange_once()
-        barrier()
-        xt = torch.tensor([(time.perf_counter() - x0) / 5], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(xt, op=dist.ReduceOp.MAX)
-        x_ms = float(xt.item()) * 1e3
-        exchange_stats = {"rows_received_per_rank_per_layer": recv_rows, "bytes_received_per_rank_per_layer": recv_rows * row_bytes,
+            what = f"{coll} all-gather of H"
+        x_ms = time_alone(exchange_once)
+        exchange_stats = {"what": what, "rows_received_per_rank_per_layer": recv_rows,
+                          "bytes_received_per_rank_per_layer": recv_rows * row_bytes,
                           "max_bytes_per_link_per_layer": link_rows * row_bytes, "ms_alone_per_layer": x_ms,
                           "GBps_busiest_link_alone": link_rows * row_bytes / (x_ms * 1e-3) / 1e9,
-                          "note": "pack + collective without any aggregation beside it, rank 0's lists, slowest rank's time"}
+                          "note": "pack + collective without any aggregation beside it, 5 rounds between barriers, slowest rank's time"}
+        # SURVEY 8e asks for both exchanges: the no-locality form (every row of H to every rank) on the same H, in the
+        # library's all-gather and as one batch of point-to-point transfers (one per link of the fully connected node)
+        full = table if halo is None else torch.empty((n * world, hidden), dtype=torch.float16, device=device)
+        ag_ms = time_alone(lambda: sdist.all_gather_into(full, D1), rounds=3)
+        p2p_ms = time_alone(lambda: sdist.all_gather_direct(full, D1, bounds, rank), rounds=3)
+        per_link = n * row_bytes
+        allgather_stats = {"what": f"all-gather of H [{n * world} x {hidden}] f16 alone, {world} ranks over {coll}",
+                           "bytes_received_per_rank_per_layer": n * (world - 1) * row_bytes, "bytes_per_link_per_layer": per_link,
+                           "all_gather_into_tensor_ms": ag_ms, "all_gather_into_tensor_GBps_per_link": per_link / (ag_ms * 1e-3) / 1e9,
+                           "point_to_point_batch_ms": p2p_ms, "point_to_point_batch_GBps_per_link": per_link / (p2p_ms * 1e-3) / 1e9,
+                           "note": "per-link rate = one rank's block over the time: a direct exchange runs every link at it, "
+                                   "a ring moves (ranks - 1) blocks over each link in turn"}
+        del full
 
     # dominant kernel: the A.H aggregation (spmm_kernel), timed by events the launch path
     # recorded on its own stream inside the timed region
@@ -387,14 +482,20 @@ def main():
     b_alg = agg_nnz * (4 + es + hidden * es) + (n + 1) * 4 + n * hidden * out_es   # SURVEY 8d, no-reuse gather model
     b_min = nnz * (4 + es) + (n + 1) * 4 + (n + n_cols) * hidden * es          # compulsory traffic
     achieved = b_alg / (agg_avg_ms * 1e-3) / 1e9
-    traffic = None
-    if world == 1 and os.path.exists(args.traffic_file):        # PMC bytes were collected on the one-GPU launch
+    # HBM-side bytes per launch of the dominant kernel: NOT measured in this run -- counters need their own rocprofv3
+    # --pmc passes (tools/prof_round.sh); the committed summary of those passes is quoted with its source
+    traffic, traffic_source = None, None
+    if world == 1 and os.path.exists(args.traffic_file):
         try:
             tf = json.load(open(args.traffic_file))
             if tf.get("workload") == args.workload:
                 traffic = tf.get("hbm_bytes_per_launch")
+                traffic_source = f"offline rocprofv3 --pmc passes of this workload, {tf.get('source')} (tag {tf.get('tag')}); not collected in this run"
         except (ValueError, OSError):
             traffic = None
+    lanes_per_row = 1
+    while lanes_per_row * 8 < hidden and lanes_per_row < 64:
+        lanes_per_row *= 2
 
     # the roof a plain copy reaches on this very device (SURVEY 8d asks for it next to the nominal 8 TB/s)
     copy_gbps = None
@@ -432,22 +533,27 @@ def main():
                    "layer1": "gemm_mode=0 sparse X, relu=1" if wl["x_density"] else "gemm_mode=1 dense X, relu=1",
                    "layer2": "gemm_mode=1 dense X, relu=0",
                    "exchange": "none" if world == 1 else
-                   (f"RCCL all-to-all of halo rows of H per layer ({sum(halo.recv_counts)} rows received per rank)"
-                    + (", overlapped with the aggregation of the own-partition edges" if exchange == "halo-overlap" else "")
-                    if halo is not None else "RCCL all-gather of H per layer"),
+                   (f"{coll} all-to-all of halo rows of H per layer ({sum(halo.recv_counts)} rows received per rank), HIP pack kernel"
+                    + (" on a side stream, overlapped with the aggregation of the own-partition edges" if exchange == "halo-overlap" else "")
+                    if halo is not None else f"{coll} all-gather of H per layer"),
                    "cut": None if world == 1 else args.cut, "boundary": None if world == 1 else args.boundary},
-        "roofline": {"bound": "hbm", "kernel": "spmm_kernel<f16,8,8> (A.H aggregation"
-                     + (", own-partition pass)" if (world > 1 and exchange == "halo-overlap") else ")"),
+        "backend": dist_backend, "world_size": dist_world, "devices": devices, "exchange_fallback": exchange_fallback,
+        "roofline": {"bound": "hbm", "kernel": ("refhalf_csr_rows_kernel" if args.exact else f"spmm_kernel<f16,8,{lanes_per_row}>")
+                     + " (A.H aggregation" + (", own-partition pass)" if (world > 1 and exchange == "halo-overlap") else ")"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": b_alg, "compulsory_bytes_per_launch": b_min,
                      "avg_launch_ms": agg_avg_ms, "min_launch_ms": agg_ms[0], "launches_timed": len(agg_ms),
                      "agg_edges_per_s": agg_nnz / (agg_avg_ms * 1e-3),
                      "stream_copy_GBps_this_device": copy_gbps},
     }
     if exchange_stats is not None:
         line["exchange"] = exchange_stats
+        line["exchange_allgather"] = allgather_stats
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)
+        line["cpu_baseline"]["reference_formulation"] = cpu_reference_formulation(torch, ops, A, X, W1t, W2t,
+                                                                                  min(args.cpu_sample_frac, 0.125))
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

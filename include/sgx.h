@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 102
+#define SGX_VERSION 103
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -283,6 +283,20 @@ int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n
                       void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan, float *s_scratch,
                       void *stream);
 
+/* The same aggregate for one rank of a node-partitioned graph: a row without a live edge receives `fill`
+ * (fp32 [n_feat], device) -- the mean of the rows of Wh of ALL n_nodes nodes, which the caller reduces across ranks
+ * (sgx_col_sums per rank, one all-reduce of n_feat floats) -- and S = 1/n_nodes on its stored edges: the reference's
+ * uniform softmax over every node (SG.py:638-641), which one rank's table (own rows + halo rows) cannot give.
+ * fill = NULL: such rows give 0.  Scratch: sgx_gat_scratch_bytes(n_cols, n_feat, n_heads, 0, plan). */
+int sgx_gat_aggregate_fill(int dtype, int relu, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
+                           const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                           const void *Wh, int64_t ldh, const void *attention, void *D, int64_t ldd, float *E, float *S,
+                           const float *fill, int64_t n_nodes, const sgx_plan *plan, float *s_scratch, void *stream);
+/* out[j] = sum over rows of X[r][j], fp32, slab sums added in a fixed order (bitwise reproducible).
+ * scratch: sgx_col_sums_scratch_bytes(n_feat) bytes. */
+size_t sgx_col_sums_scratch_bytes(int n_feat);
+int sgx_col_sums(int dtype, int n_rows, int n_feat, const void *X, int64_t ldx, float *out, float *scratch, void *stream);
+
 /* ---- helpers on either side of the path (SURVEY 8f "next" rows) -------------------- */
 
 /* Checks rowPtr[0]==0, monotone, rowPtr[n_rows]==nnz and 0 <= columnIndex < n_cols on the
@@ -327,6 +341,12 @@ int sgx_readout_mean_linear(int dtype, int n_graphs, int F, int C, const void *X
 /* ReLU backward of RPYNQ (MOL cell 16): grad[i] = (out[i] == 0) ? 0 : grad[i], in place. */
 int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
                            void *stream);
+
+/* dst[i][0:n_feat] = src[row_index[i]][0:n_feat], i in [0, n_rows): the pack step of the halo exchange between the
+ * GPUs of a node -- the rows of H a peer's edges reference, gathered into the send buffer of the all-to-all (the
+ * block select of dsp_kernel_float_adj_4, K.cpp:217-264, done on the sending side).  ld_* in elements. */
+int sgx_pack_rows(int dtype, int64_t n_rows, int n_feat, const void *src, int64_t ld_src, const int32_t *row_index,
+                  void *dst, int64_t ld_dst, void *stream);
 
 /* A plain streaming copy (16 bytes per lane, non-temporal), the kernel the attainable HBM rate of a device is
  * measured with next to the nominal 8 TB/s (bench.py reports it as roofline.stream_copy_GBps_this_device).

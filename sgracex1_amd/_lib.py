@@ -29,6 +29,7 @@ SYMBOLS = [
     "sgx_gat_aggregate", "sgx_gat_scratch_bytes", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
     "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear", "sgx_gat_backward_edges",
     "sgx_stream_copy", "sgx_xw_dense_act", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
+    "sgx_gat_aggregate_fill", "sgx_col_sums", "sgx_col_sums_scratch_bytes", "sgx_pack_rows",
     "sgx_version", "sgx_status_string",
 ]
 
@@ -125,6 +126,15 @@ def _load():
     lib.sgx_gat_aggregate.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
                                       vp, c_i64, vp, vp, vp, vp, vp]
     lib.sgx_gat_aggregate.restype = c_int
+    lib.sgx_gat_aggregate_fill.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, vp, vp, vp, vp, c_i64, vp,
+                                           vp, c_i64, vp, vp, vp, c_i64, vp, vp, vp]
+    lib.sgx_gat_aggregate_fill.restype = c_int
+    lib.sgx_col_sums_scratch_bytes.argtypes = [c_int]
+    lib.sgx_col_sums_scratch_bytes.restype = sz
+    lib.sgx_col_sums.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, vp, vp]
+    lib.sgx_col_sums.restype = c_int
+    lib.sgx_pack_rows.argtypes = [c_int, c_i64, c_int, vp, c_i64, vp, vp, c_i64, vp]
+    lib.sgx_pack_rows.restype = c_int
     lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]
     lib.sgx_csr_validate.restype = c_int
     lib.sgx_coo_to_csr.argtypes = [vp, c_i64, c_int, vp, vp]

@@ -513,6 +513,7 @@ struct GatArgs {
     void *D;
     float *E, *S, *s;
     const float *fill;
+    int uniform_n;             // the N of the uniform softmax a dead row gets (S = 1/N): n_cols, or all nodes of a partitioned graph
     float out_scale;           // deq_o of the quantised layer on fp32 outputs (0 = off)
     const sgx_plan *plan;      // long rows -> split path
     float *split;              // scratch of the split path, behind the scores / column means
@@ -549,14 +550,14 @@ int gat_launch_one(const GatArgs &a)
             row_l = row_m + (size_t)hp->n_long * a.n_heads;
         }
         hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, false>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows,
-                           a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
+                           a.uniform_n, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
                            a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill,
                            share, thr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, a.out_scale);
         SGX_LAUNCH_CHECK();
         if (thr > 0) {
             const unsigned tgrid = (unsigned)((hp->n_tasks + rows_per_block - 1) / rows_per_block);
             hipLaunchKernelGGL((gat_aggregate_heads_kernel<T, VEC, LPR, true>), dim3(tgrid), dim3(kBlock), 0, a.stream,
-                               hp->n_tasks, a.n_cols, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val,
+                               hp->n_tasks, a.uniform_n, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, (const T *)a.val,
                                (const T *)a.Wh, a.h_bytes, a.ld_bytes, h1, h2, a.alpha, (T *)a.D, a.ldd, a.relu, a.E, nullptr,
                                a.vec_store, nullptr, share, 0, hp->task_row, hp->task_e0, hp->task_e1, pacc, ldp, pm, pl,
                                a.out_scale);
@@ -567,7 +568,7 @@ int gat_launch_one(const GatArgs &a)
                                pm, pl, (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
             SGX_LAUNCH_CHECK();
             if (a.S) {
-                hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(hp->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols,
+                hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(hp->n_long, 16), dim3(kBlock), 0, a.stream, a.uniform_n,
                                    a.n_heads, hp->long_row, a.rowptr, a.col, (const T *)a.val, h1, h2, a.alpha, row_m, row_l,
                                    a.fill != nullptr, a.S);
                 SGX_LAUNCH_CHECK();
@@ -595,13 +596,13 @@ int gat_launch_one(const GatArgs &a)
                            a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
         SGX_LAUNCH_CHECK();
         if (a.S) {
-            hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_cols, 1,
+            hipLaunchKernelGGL((gat_split_softmax_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.uniform_n, 1,
                                p->long_row, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, row_m, row_l,
                                a.fill != nullptr, a.S);
             SGX_LAUNCH_CHECK();
         }
     }
-    hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.n_cols, a.n_feat,
+    hipLaunchKernelGGL((gat_aggregate_kernel<T, VEC, LPR>), dim3(grid), dim3(kBlock), 0, a.stream, a.n_rows, a.uniform_n, a.n_feat,
                        a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes, s1, s2, a.alpha,
                        (T *)a.D, a.ldd, a.relu, a.E, a.S, a.vec_store, a.fill, long_thr, a.out_scale);
     SGX_LAUNCH_CHECK();
@@ -656,10 +657,49 @@ extern "C" int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_
                                 Wh, ldh, attention, D, ldd, E, S, plan, s_scratch, (hipStream_t)stream, 0.0f);
 }
 
+extern "C" int sgx_gat_aggregate_fill(int dtype, int relu, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
+                                      const int32_t *rowPtr, const int32_t *columnIndex, const void *values,
+                                      const void *Wh, int64_t ldh, const void *attention, void *D, int64_t ldd, float *E, float *S,
+                                      const float *fill, int64_t n_nodes, const sgx_plan *plan, float *s_scratch, void *stream)
+{
+    if (fill && (n_nodes < 1 || n_nodes > 0x7FFFFFFF)) return SGX_ERR_SHAPE;
+    return sgx_gat_aggregate_ep(dtype, relu, 0, n_rows, n_cols, n_feat, n_heads, alpha, rowPtr, columnIndex, values, Wh, ldh,
+                                attention, D, ldd, E, S, plan, s_scratch, (hipStream_t)stream, 0.0f, fill, (int)n_nodes);
+}
+
+namespace {
+__global__ __launch_bounds__(kBlock) void col_sum_finish_kernel(int n_feat, const float *__restrict__ partial, float *__restrict__ out)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_feat) return;
+    float s = 0.0f;
+    for (int b = 0; b < kMeanSlabs; ++b) s += partial[(int64_t)b * n_feat + j];
+    out[j] = s;
+}
+}  // namespace
+
+extern "C" size_t sgx_col_sums_scratch_bytes(int n_feat) { return n_feat < 1 ? 0 : (size_t)kMeanSlabs * n_feat * sizeof(float); }
+
+extern "C" int sgx_col_sums(int dtype, int n_rows, int n_feat, const void *X, int64_t ldx, float *out, float *scratch, void *stream)
+{
+    if (n_rows < 0 || n_feat < 1 || ldx < n_feat) return SGX_ERR_SHAPE;
+    if (!out || !scratch || (n_rows > 0 && !X)) return SGX_ERR_NULL;
+    if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SGX_F16)
+        hipLaunchKernelGGL(col_sum_slab_kernel<f16>, dim3(kMeanSlabs), dim3(kBlock), 0, s, n_rows, n_feat, (const f16 *)X, ldx, scratch);
+    else
+        hipLaunchKernelGGL(col_sum_slab_kernel<float>, dim3(kMeanSlabs), dim3(kBlock), 0, s, n_rows, n_feat, (const float *)X, ldx, scratch);
+    SGX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_sum_finish_kernel, dim3((n_feat + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n_feat, scratch, out);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
                          const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
                          const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
-                         float *s_scratch, hipStream_t stream, float out_scale)
+                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill, int ext_n)
 {
     if (n_heads < 1) n_heads = 1;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
@@ -677,7 +717,8 @@ int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, in
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = stream; a.out_scale = out_scale;
-    a.fill = nullptr;
+    a.fill = ext_fill;                       // a caller-provided row for dead rows (partitioned graph), or the means below
+    a.uniform_n = ext_fill ? ext_n : n_cols;
     a.plan = uses_split(plan) ? plan : nullptr;
     a.split = s_scratch + base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
     if (fill_dead_rows) {

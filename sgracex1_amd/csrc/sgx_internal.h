@@ -114,4 +114,4 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
                          const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
                          const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
-                         float *s_scratch, hipStream_t stream, float out_scale);
+                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill = nullptr, int ext_n = 0);

@@ -111,6 +111,29 @@ __global__ __launch_bounds__(kBlock) void repitch_rows_kernel(const char *__rest
     }
 }
 
+// dst[i][:] = src[row_index[i]][:]: the pack step of the halo exchange (rows of H a peer asked for, gathered into the
+// send buffer).  One lane per 16-byte chunk of a packed row: the reads are whole rows at random places, the writes
+// stream.  A row's last chunk is cut to row_bytes on both sides.
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(const char *__restrict__ src, int64_t src_pitch,
+                                                           const int32_t *__restrict__ row_index, char *__restrict__ dst,
+                                                           int64_t dst_pitch, int row_bytes, int64_t n_rows)
+{
+    const int chunks = (row_bytes + 15) / 16;
+    const int64_t total = n_rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / chunks;
+        const int k = (int)(i - r * chunks);
+        const char *from = src + (int64_t)row_index[r] * src_pitch + 16 * k;
+        char *to = dst + r * dst_pitch + 16 * k;
+        if (16 * k + 16 <= row_bytes) {
+            *reinterpret_cast<u32x4_u *>(to) = *reinterpret_cast<const u32x4_u *>(from);
+        } else {
+            for (int b = 0; 16 * k + 2 * b < row_bytes; ++b)
+                *reinterpret_cast<unsigned short *>(to + 2 * b) = *reinterpret_cast<const unsigned short *>(from + 2 * b);
+        }
+    }
+}
+
 int grid_1d(int64_t n)
 {
     int64_t b = (n + kBlock - 1) / kBlock;
@@ -185,6 +208,23 @@ int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(repitch_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, (const char *)src, src_pitch,
                        (char *)dst, dst_pitch, row_bytes, n_rows);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+extern "C" int sgx_pack_rows(int dtype, int64_t n_rows, int n_feat, const void *src, int64_t ld_src, const int32_t *row_index,
+                             void *dst, int64_t ld_dst, void *stream)
+{
+    if (n_rows < 0 || n_feat < 1 || ld_src < n_feat || ld_dst < n_feat) return SGX_ERR_SHAPE;
+    if (n_rows == 0) return SGX_OK;
+    if (!src || !dst || !row_index) return SGX_ERR_NULL;
+    if (dtype != SGX_F16 && dtype != SGX_F32) return SGX_ERR_UNSUPPORTED;
+    const int64_t es = (int64_t)sgx_elem_size(dtype);
+    const int64_t total = n_rows * ((n_feat * es + 15) / 16);
+    int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const char *)src,
+                       ld_src * es, row_index, (char *)dst, ld_dst * es, (int)(n_feat * es), n_rows);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }

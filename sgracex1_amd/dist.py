@@ -60,6 +60,39 @@ def all_gather_into(out, inp, group=None):
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def all_reduce_sum(t, group=None):
+    """In-place sum over the ranks (a handful of floats: the column sums behind the GAT layer's dead-row rule)."""
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_gather_direct(out, inp, bounds, rank, group=None):
+    """The all-gather of H as one batch of point-to-point transfers: every rank sends its block to every peer and
+    receives every peer's block straight into its place -- (world - 1) concurrent transfers per rank, one per xGMI
+    link of the fully connected node ('direct' rather than ring, whose 7 serial steps each wait on one
+    link).  RCCL runs the batch as one group of send/recv pairs."""
+    world = len(bounds) - 1
+    lo, hi = bounds[rank], bounds[rank + 1]
+    staged = _host_staged(inp, group) or (out.is_cuda and dist.get_backend(group) == "gloo")
+    src = inp.cpu().contiguous() if staged else inp.contiguous()
+    dst = torch.empty(out.shape, dtype=out.dtype) if staged else out
+    ops_ = []
+    for step in range(1, world):                      # peer order staggered by rank: no two ranks start on the same target
+        to, frm = (rank + step) % world, (rank - step) % world
+        ops_.append(dist.P2POp(dist.isend, src, to, group=group))
+        ops_.append(dist.P2POp(dist.irecv, dst[bounds[frm]:bounds[frm + 1]], frm, group=group))
+    for w in (dist.batch_isend_irecv(ops_) if ops_ else []):
+        w.wait()
+    dst[lo:hi] = src
+    if staged:
+        out.copy_(dst)
+
+
 def all_to_all_rows(out, inp, out_splits, in_splits, group=None):
     if _host_staged(inp, group) or (out.is_cuda and dist.get_backend(group) == "gloo"):
         o = torch.empty(out.shape, dtype=out.dtype)
@@ -79,6 +112,8 @@ class HaloPlan:
     send_counts: List[int]            # rows sent to each peer
     recv_counts: List[int]            # rows received from each owner
     n_own: int
+    send_rows32: Optional[torch.Tensor] = None    # the same ids as int32 (what the pack kernel reads)
+    any_dead_rows: Optional[bool] = None          # GAT: does ANY rank hold a row without a live edge (decided once)
 
     @property
     def n_table(self):
@@ -116,8 +151,9 @@ def build_halo_plan(col_global: torch.Tensor, bounds: List[int], rank: int, grou
     req_out = torch.cat(need) if sum(recv_counts) else col64.new_empty(0)
     req_in = col64.new_empty(sum(send_counts))
     all_to_all_rows(req_in, req_out, send_counts, recv_counts, group=group)
-    return HaloPlan(bounds, rank, col_compact.to(torch.int32), (req_in - lo).contiguous(), send_counts, recv_counts,
-                    hi - lo)
+    send_rows = (req_in - lo).contiguous()
+    return HaloPlan(bounds, rank, col_compact.to(torch.int32), send_rows, send_counts, recv_counts, hi - lo,
+                    send_rows32=send_rows.to(torch.int32))
 
 
 @dataclass
@@ -129,8 +165,10 @@ class Backend:
     spmm: Callable
     spmm_partial: Optional[Callable] = None
     spmm_finish: Optional[Callable] = None
-    gat: Optional[Callable] = None      # gat(adj_compact, table, attention, alpha, relu) -> D_local (edge softmax)
+    gat: Optional[Callable] = None      # gat(adj_compact, table, attention, alpha, relu, fill_row, n_nodes) -> D_local
     xw_act: Optional[Callable] = None   # xw_act(Z_local, Wt, relu) -> act(Z.W): second stage of the aggregate-first order
+    pack: Optional[Callable] = None     # pack(h_local, send_rows32) -> rows gathered into a send buffer, on the current stream
+    col_sums: Optional[Callable] = None  # col_sums(h_local) -> fp32 [P] column sums of the rank's rows
 
 
 def hip_backend():
@@ -145,9 +183,10 @@ def hip_backend():
     return Backend(xw=xw, spmm=lambda adj, table, relu: ops.spmm(adj, table, relu=relu),
                    spmm_partial=lambda adj, table: ops.spmm_acc(adj, table, partial_out=True),
                    spmm_finish=lambda adj, table, partial, relu: ops.spmm_acc(adj, table, relu=relu, acc_in=partial),
-                   gat=lambda adj, table, att, alpha, relu: ops.gat_aggregate(adj, table, att, alpha=alpha, relu=relu,
-                                                                              fill_dead_rows=False),
-                   xw_act=lambda Z, Wt, relu: ops.xw_dense(Z, Wt, relu=relu))
+                   gat=lambda adj, table, att, alpha, relu, fill_row=None, n_nodes=None: ops.gat_aggregate(
+                       adj, table, att, alpha=alpha, relu=relu, fill_dead_rows=False, fill_row=fill_row, n_nodes=n_nodes),
+                   xw_act=lambda Z, Wt, relu: ops.xw_dense(Z, Wt, relu=relu),
+                   pack=lambda h, rows32: ops.pack_rows(h, rows32), col_sums=lambda h: ops.col_sums(h))
 
 
 def _stages(backend: Backend, fea_local, Wt, relu, aggregate_first):
@@ -162,16 +201,29 @@ def _stages(backend: Backend, fea_local, Wt, relu, aggregate_first):
     return fea_local, False, lambda z: backend.xw_act(z, Wt, relu)
 
 
+def _pack(backend: Backend, h_local, plan: HaloPlan):
+    """The rows the peers asked for, gathered into one send buffer (HIP pack kernel; index_select without one)."""
+    if not plan.send_rows.numel():
+        return h_local.new_empty((0, h_local.shape[1]))
+    if backend.pack is not None and plan.send_rows32 is not None:
+        return backend.pack(h_local, plan.send_rows32)
+    return h_local.index_select(0, plan.send_rows)
+
+
 def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, group=None, h_global=None,
-                    aggregate_first=False):
-    """adj_local: rows of this rank, GLOBAL column indices.  Returns D_local."""
+                    aggregate_first=False, direct=False, rank=None):
+    """adj_local: rows of this rank, GLOBAL column indices.  Returns D_local.
+    direct: the gather as one batch of point-to-point transfers (all_gather_direct) instead of the library's
+    all_gather_into_tensor."""
     world = len(bounds) - 1
     h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
     sizes = [bounds[g + 1] - bounds[g] for g in range(world)]
     P = h_local.shape[1]
     if h_global is None:
         h_global = torch.empty((bounds[-1], P), dtype=h_local.dtype, device=h_local.device)
-    if len(set(sizes)) == 1:
+    if direct:
+        all_gather_direct(h_global, h_local, bounds, dist.get_rank(group) if rank is None else rank, group=group)
+    elif len(set(sizes)) == 1:
         all_gather_into(h_global, h_local.contiguous(), group=group)
     else:
         # unequal blocks (nnz-balanced partition): gather blocks padded to the largest, then compact
@@ -186,12 +238,16 @@ def layer_allgather(backend: Backend, adj_local, fea_local, Wt, relu, bounds, gr
 
 
 def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPlan, group=None, table=None,
-               attention=None, alpha=0.2, aggregate_first=False):
+               attention=None, alpha=0.2, aggregate_first=False, fill_dead_rows=None):
     """adj_compact: rows of this rank with column indices already remapped by build_halo_plan.
     attention: the GAT vector a [2P] -> the edge-softmax aggregate instead of A.H.  The softmax is
     row-local, so the same halo rows serve it: the scores Wh.a2 of the halo rows are recomputed from
-    the received rows, own row r is row r of the compact table.  (Rows left without a live edge give
-    0 here: the dense emulation's mean over ALL nodes would need one more reduction across ranks.)"""
+    the received rows, own row r is row r of the compact table.
+    Rows without a live edge (GAT): the reference's masked dense row is constant, its softmax uniform over ALL
+    nodes, the row receives the mean of all rows of Wh (SG.py:638-641).  One rank sees only its own and its halo
+    rows, so the column sums of every rank's rows are all-reduced (P floats) and the mean is handed to the
+    aggregate -- the same result as on one GPU.  fill_dead_rows: None = do this when any rank holds such a row
+    (decided once per plan with one all-reduce of a flag), True / False = always / never (then such rows give 0)."""
     if aggregate_first and attention is not None:
         raise ValueError("the edge softmax needs Wh: no aggregate-first order for GAT")
     h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
@@ -199,11 +255,33 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     if table is None:
         table = torch.empty((plan.n_table, P), dtype=h_local.dtype, device=h_local.device)
     table[:plan.n_own] = h_local
-    packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
+    packed = _pack(backend, h_local, plan)
     all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
     if attention is not None:
-        return backend.gat(adj_compact, table, attention, alpha, relu)
+        if fill_dead_rows is None:
+            if plan.any_dead_rows is None:
+                local = bool(getattr(adj_compact, "has_dead_rows", True))      # without the attribute: assume so
+                flag = torch.tensor([float(local)], dtype=torch.float32, device=h_local.device)
+                plan.any_dead_rows = bool(all_reduce_sum(flag, group=group).item() > 0)
+            fill_dead_rows = plan.any_dead_rows
+        if not fill_dead_rows:
+            return backend.gat(adj_compact, table, attention, alpha, relu)
+        if backend.col_sums is None:
+            raise ValueError("rows without a live edge need a backend with col_sums (the mean row of all nodes)")
+        sums = all_reduce_sum(backend.col_sums(h_local).to(torch.float32), group=group)
+        n_nodes = plan.bounds[-1]
+        return backend.gat(adj_compact, table, attention, alpha, relu, sums / float(n_nodes), n_nodes)
     return finish(backend.spmm(adj_compact, table, relu))
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def split_own_halo(rowptr, col_compact, val, n_own):
@@ -234,14 +312,20 @@ def layer_halo_overlap(backend: Backend, adj_own, adj_halo, fea_local, Wt, relu,
     n_halo = sum(plan.recv_counts)
     if halo_table is None:
         halo_table = torch.empty((n_halo, P), dtype=h_local.dtype, device=h_local.device)
-    packed = h_local.index_select(0, plan.send_rows) if plan.send_rows.numel() else h_local.new_empty((0, P))
-    staged = _host_staged(packed, group) or (halo_table.is_cuda and dist.get_backend(group) == "gloo")
+    on_gloo = dist.get_backend(group) == "gloo"
     work = None
-    if staged or dist.get_backend(group) == "gloo":
-        all_to_all_rows(halo_table[:n_halo], packed, plan.recv_counts, plan.send_counts, group=group)      # no async on gloo
+    if on_gloo or not h_local.is_cuda:
+        # no asynchronous collective on gloo: pack, exchange, then aggregate (the rehearsal path)
+        all_to_all_rows(halo_table[:n_halo], _pack(backend, h_local, plan), plan.recv_counts, plan.send_counts, group=group)
     else:
-        work = dist.all_to_all_single(halo_table[:n_halo], packed, output_split_sizes=plan.recv_counts,
-                                      input_split_sizes=plan.send_counts, group=group, async_op=True)
+        # pack kernel and collective on a side stream: the aggregation of the own-partition edges below starts on
+        # the compute stream right away instead of behind the pack
+        side = _side_stream(h_local.device)
+        side.wait_stream(torch.cuda.current_stream())          # H is complete
+        with torch.cuda.stream(side):
+            packed = _pack(backend, h_local, plan)
+            work = dist.all_to_all_single(halo_table[:n_halo], packed, output_split_sizes=plan.recv_counts,
+                                          input_split_sizes=plan.send_counts, group=group, async_op=True)
     partial = backend.spmm_partial(adj_own, h_local)          # a view with padded rows is fine: the kernels take a row pitch
     if work is not None:
         work.wait()

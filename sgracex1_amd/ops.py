@@ -476,11 +476,13 @@ def requantize_(H, scale_fea, internal_bits):
 
 
 def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=False, fill_dead_rows=None, out=None,
-                  heads=1, use_plan=True):
+                  heads=1, use_plan=True, fill_row=None, n_nodes=None):
     """Edge-softmax aggregate over an already computed Wh [adj.n_cols, F]; row r of adj is node r of Wh.
     heads > 1: F/heads columns per head, attention = heads vectors of 2*F/heads (E, S become [nnz, heads]).
     fill_dead_rows: None = decide from the adjacency (rows without a positive entry get the mean of
-    all rows of Wh, as in the reference's dense emulation), False = such rows give 0."""
+    all rows of Wh, as in the reference's dense emulation), False = such rows give 0.
+    fill_row (fp32 [F]) with n_nodes: one rank of a partitioned graph -- dead rows receive this row (the mean over
+    ALL nodes, reduced across ranks by the caller) and S = 1/n_nodes (sgx_gat_aggregate_fill)."""
     _dev2d(Wh, "Wh")
     code = dtype_code(Wh.dtype)
     N, F = Wh.shape
@@ -498,13 +500,50 @@ def gat_aggregate(adj, Wh, attention, alpha=0.2, relu=False, want_edge_outputs=F
         es_shape = (adj.nnz,) if heads == 1 else (adj.nnz, heads)
         E = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
         S = torch.empty(es_shape, dtype=torch.float32, device=Wh.device)
-    fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
     plan = adj.gat_plan.handle if (use_plan and adj.wants_plan) else None
+    if fill_row is not None:
+        _dev(fill_row, "fill_row")
+        if fill_row.dtype != torch.float32 or fill_row.numel() != F or not n_nodes:
+            raise ValueError("fill_row must be float32 [F] and come with n_nodes")
+        s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, 0, plan) // 4, dtype=torch.float32, device=Wh.device)
+        check(lib.sgx_gat_aggregate_fill(code, int(bool(relu)), adj.n_rows, N, F, heads, float(alpha), _ptr(adj.rowptr),
+                                         _ptr(adj.col), _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out),
+                                         out.stride(0), _ptr(E), _ptr(S), _ptr(fill_row.contiguous()), int(n_nodes), plan,
+                                         _ptr(s), _stream()), "sgx_gat_aggregate_fill")
+        return (out, E, S) if want_edge_outputs else out
+    fill = int(adj.has_dead_rows if fill_dead_rows is None else bool(fill_dead_rows))
     s = torch.empty(lib.sgx_gat_scratch_bytes(N, F, heads, fill, plan) // 4, dtype=torch.float32, device=Wh.device)
     check(lib.sgx_gat_aggregate(code, int(bool(relu)), fill, adj.n_rows, N, F, heads, float(alpha), _ptr(adj.rowptr), _ptr(adj.col),
                                 _ptr(adj.val), _ptr(Wh), Wh.stride(0), _ptr(att), _ptr(out), out.stride(0),
                                 _ptr(E), _ptr(S), plan, _ptr(s), _stream()), "sgx_gat_aggregate")
     return (out, E, S) if want_edge_outputs else out
+
+
+def col_sums(X, n_feat=None):
+    """fp32 column sums of the rows of X [n, F] in a fixed order (sgx_col_sums): a rank's share of the mean row the
+    partitioned GAT layer gives rows without a live edge."""
+    _dev2d(X, "X")
+    F = X.shape[1] if n_feat is None else n_feat
+    out = torch.empty(F, dtype=torch.float32, device=X.device)
+    scratch = torch.empty(lib.sgx_col_sums_scratch_bytes(F) // 4, dtype=torch.float32, device=X.device)
+    check(lib.sgx_col_sums(dtype_code(X.dtype), X.shape[0], F, _ptr(X), X.stride(0), _ptr(out), _ptr(scratch), _stream()),
+          "sgx_col_sums")
+    return out
+
+
+def pack_rows(src, row_index, out=None, stream=None):
+    """out[i] = src[row_index[i]] (sgx_pack_rows): the rows of H a peer asked for, gathered into the send buffer of
+    the halo exchange.  row_index int32 on the device; stream: a torch stream other than the current one to launch on."""
+    _dev2d(src, "src")
+    _dev(row_index, "row_index")
+    if row_index.dtype != torch.int32:
+        raise TypeError("row_index must be int32")
+    n, F = row_index.numel(), src.shape[1]
+    out = _out(out, n, F, src.dtype, src.device)
+    st = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(lib.sgx_pack_rows(dtype_code(src.dtype), n, F, _ptr(src), src.stride(0), _ptr(row_index), _ptr(out), out.stride(0), st),
+          "sgx_pack_rows")
+    return out
 
 
 def xt_g(X, G):

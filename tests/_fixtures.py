@@ -35,7 +35,7 @@ def known_answers():
         return json.load(f)
 
 
-# The csim log's two entries that the checked-in kernel source does not print (tools/csim_residual.py,
+# The csim log's two entries that the checked-in kernel source does not print (tests/csim_residual.py,
 # profiles/r02_csim_residual.txt): one binary16 ulp each, the model's magnitude above the log's.  (row, col) -> what the
 # reference-half arithmetic prints there.  Every other of the 42 logged values is reproduced to the printed digit.
 CSIM_RESIDUAL = {(0, 10): "0.0995483", (31, 18): "-0.0348816"}

@@ -6,7 +6,7 @@ shows no setting or reading of the checked-in kernel source (K.cpp:815-895, :177
 Uses the committed fixtures only (tests/golden/citeseer.npz, known_answers.json) and the oracle (test
 infrastructure).  Output kept under profiles/r02_csim_residual.txt.
 
-    python tools/csim_residual.py            # a few minutes on one core
+    python tests/csim_residual.py            # a few minutes on one core
 """
 import itertools
 import math
@@ -198,4 +198,4 @@ def conv(a32, mode, only=None):
 table("3d. how the text values become half (text -> float -> half with nearest-even | ties away | truncation)",
       [("weights %s, adjacency %s" % v, model(Wh=conv(W32, v[0], need_cols), Ah=conv(ava.astype(np.float32), v[1])))
        for v in itertools.product(("rne", "away", "trunc"), ("rne", "away", "trunc"))])
-print("\nEvery variant leaves (0,10); the checked-in source read literally (the oracle's model) is the only one at 2 mismatches.")
+print("\nNo variant prints (0,10) and none gets below 2 mismatches: the log was written by a kernel revision that differs from the checked-in source.")

@@ -62,7 +62,7 @@ def _worker(rank, world, port, tmp, balance_nnz):
             out = partial + spmm(adj, table, False)
             return torch.clamp(out, min=0) if relu else out
 
-        def gat(adj, table, att, alpha, relu):                  # SG.py:634-661 on the rank's rows, dense
+        def gat(adj, table, att, alpha, relu, fill_row=None, n_nodes=None):    # SG.py:634-661 on the rank's rows, dense
             n_loc, n_tab = adj.rowptr.numel() - 1, table.shape[0]
             deg = (adj.rowptr[1:] - adj.rowptr[:-1]).long()
             rows = torch.repeat_interleave(torch.arange(n_loc), deg)
@@ -71,15 +71,20 @@ def _worker(rank, world, port, tmp, balance_nnz):
             Pn = table.shape[1]
             e = torch.nn.functional.leaky_relu((table[:n_loc] @ att[:Pn])[:, None] + (table @ att[Pn:])[None, :], alpha)
             a = torch.softmax(torch.where(mask > 0, e, torch.full_like(e, -9e15)), dim=1)
-            a = torch.where(mask.sum(1, keepdim=True) > 0, a, torch.zeros_like(a))
+            dead = mask.sum(1, keepdim=True) == 0
+            a = torch.where(dead, torch.zeros_like(a), a)
             out = a @ table
+            if fill_row is not None:                              # the mean row of ALL nodes, reduced by layer_halo
+                assert n_nodes == n
+                out = torch.where(dead, fill_row[None, :].to(out.dtype), out)
             return torch.clamp(out, min=0) if relu else out
 
         def xw_act(z, Wt_, relu):
             out = z @ Wt_.t()
             return torch.clamp(out, min=0) if relu else out
 
-        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish, gat=gat, xw_act=xw_act)
+        backend = D.Backend(xw=xw, spmm=spmm, spmm_partial=spmm_partial, spmm_finish=spmm_finish, gat=gat, xw_act=xw_act,
+                            col_sums=lambda h: h.double().sum(0).float())
         trp, tci, tva = torch.as_tensor(rp), torch.as_tensor(ci), torch.as_tensor(va)
         bounds = D.row_partition(n, world, trp if balance_nnz else None)
         assert bounds[0] == 0 and bounds[-1] == n and all(b1 >= b0 for b0, b1 in zip(bounds, bounds[1:]))
@@ -138,11 +143,23 @@ def _worker(rank, world, port, tmp, balance_nnz):
         deg_all = np.diff(rp)
         pos[np.repeat(np.arange(n), deg_all), ci.astype(np.int64)] = torch.as_tensor((va > 0).astype(np.float32))
         e_all = torch.nn.functional.leaky_relu((H_all @ att[:p])[:, None] + (H_all @ att[p:])[None, :], 0.2)
+        # the reference's formula as it stands (SG.py:638-641): a row without a positive entry keeps -9e15 everywhere,
+        # its softmax is uniform over ALL n nodes and it receives the mean of all rows of Wh -- also when the rows of
+        # Wh live on other ranks (rows without any edge are 10 % of this graph, and every rank holds some)
         a_all = torch.softmax(torch.where(pos > 0, e_all, torch.full_like(e_all, -9e15)), dim=1)
-        a_all = torch.where(pos.sum(1, keepdim=True) > 0, a_all, torch.zeros_like(a_all))
+        dead_all = pos.sum(1) == 0
+        assert bool(dead_all[lo:hi].any()) and torch.allclose(a_all[dead_all], torch.full_like(a_all[dead_all], 1.0 / n))
         want_gat = torch.clamp(a_all @ H_all, min=0)
         d4 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan, attention=att)
         np.testing.assert_allclose(d4.numpy(), want_gat[lo:hi].numpy(), rtol=1e-4, atol=1e-5)
+        assert plan.any_dead_rows is True                       # decided once, by all ranks together
+        # the cheaper sparse answer stays available: such rows give 0
+        d5 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan, attention=att,
+                          fill_dead_rows=False)
+        assert not d5[dead_all[lo:hi]].any() and torch.allclose(d5[~dead_all[lo:hi]], d4[~dead_all[lo:hi]])
+        # the all-gather as one batch of point-to-point transfers: the same table, the same result
+        d6 = D.layer_allgather(backend, LocalCsr(lrp, lci, lva, n), Xl, Wt, True, bounds, direct=True)
+        assert torch.equal(d6, d1)
         # bytes moved: the halo exchange never receives more rows than the all-gather would
         assert sum(plan.recv_counts) <= n - (hi - lo)
         sent = torch.tensor([sum(plan.send_counts)], dtype=torch.int64)

@@ -62,6 +62,27 @@ def _worker(rank, world, port, tmp):
         d4 = D.layer_halo(backend, ops.Csr(rp, plan.col_compact, va, plan.n_table), X[lo:hi].contiguous(), Wt, True, plan,
                           attention=att)
         assert torch.equal(d4, want_gat[lo:hi])
+        # rows without a live edge (every value of the row <= 0, as a coarse quantiser leaves them): one GPU gives such a
+        # row the mean of ALL rows of Wh (SG.py:638-641); the partitioned layer reduces the column sums across ranks
+        # and gives the same -- on both ranks, for dead rows of either partition
+        dead = torch.zeros(n, dtype=torch.bool, device=dev)
+        dead[torch.arange(3, n, 97, device=dev)] = True
+        rows_all = torch.repeat_interleave(torch.arange(n, device=dev), A.rowptr.diff().long())
+        val2 = torch.where(dead[rows_all], torch.zeros_like(A.val), A.val)
+        A2 = ops.Csr(A.rowptr, A.col, val2, n)
+        assert A2.has_dead_rows
+        want2, _, S2 = ops.layer_forward(A2, X, Wt, relu=True, gat_attention=att, want_edge_outputs=True)
+        rp2, ci2, va2 = D.slice_rows(A2.rowptr, A2.col, A2.val, lo, hi)
+        A2_loc = ops.Csr(rp2, plan.col_compact, va2, plan.n_table)
+        plan.any_dead_rows = None
+        d5 = D.layer_halo(backend, A2_loc, X[lo:hi].contiguous(), Wt, True, plan, attention=att)
+        assert plan.any_dead_rows is True and bool(dead[lo:hi].any())
+        assert torch.allclose(d5.float(), want2[lo:hi].float(), rtol=2e-3, atol=2e-3)
+        assert torch.equal(d5[~dead[lo:hi]], want2[lo:hi][~dead[lo:hi]])            # live rows: the same bits as before
+        H_all = ops.xw_dense(X, Wt).float()
+        assert torch.allclose(d5[dead[lo:hi]].float(), torch.relu(H_all.mean(0)).expand(int(dead[lo:hi].sum()), p), rtol=2e-3, atol=2e-3)
+        d6 = D.layer_halo(backend, A2_loc, X[lo:hi].contiguous(), Wt, True, plan, attention=att, fill_dead_rows=False)
+        assert not d6[dead[lo:hi]].any()                                             # the sparse answer stays available
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -75,8 +96,8 @@ def test_two_ranks_one_gpu_match_single_rank():
 
 
 @pytest.mark.parametrize("extra,expect", [([], "overlapped with the aggregation"),
-                                          (["--exchange", "halo"], "RCCL all-to-all of halo rows"),
-                                          (["--cut", "1.0"], "RCCL all-gather")])
+                                          (["--exchange", "halo"], "gloo all-to-all of halo rows"),
+                                          (["--cut", "1.0"], "gloo all-gather")])
 def test_bench_multi_rank_path_rehearsal(extra, expect):
     """bench.py as the driver launches it for N > 1, on the small workload, 2 ranks on one GPU over gloo:
     the default partitioned graph (halo exchange) and the no-locality case (all-gather)."""
@@ -90,7 +111,17 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "weak"
-    assert expect in rec["config"]["exchange"]
+    assert expect in rec["config"]["exchange"] and "RCCL" not in rec["config"]["exchange"]     # labelled by the backend that ran
+    # the line proves what carried the exchange: backend, the world size the process group reports, one device
+    # identity per rank, and whether the overlapped exchange had to fall back
+    assert rec["backend"] == "gloo" and rec["world_size"] == 2 and rec["exchange_fallback"] is False
+    assert len(rec["devices"]) == 2 and all("cuda:" in d for d in rec["devices"])
+    # both exchanges in the one invocation: the configured one alone, and the no-locality all-gather of H in the
+    # library's collective and as one batch of point-to-point transfers
+    ag = rec["exchange_allgather"]
+    assert ag["all_gather_into_tensor_ms"] > 0 and ag["point_to_point_batch_ms"] > 0
+    assert ag["bytes_per_link_per_layer"] == rec["config"]["nodes_per_gpu"] * rec["config"]["hidden"] * 2
+    assert abs(ag["all_gather_into_tensor_GBps_per_link"] - ag["bytes_per_link_per_layer"] / ag["all_gather_into_tensor_ms"] / 1e6) < 1e-6 * ag["all_gather_into_tensor_GBps_per_link"] + 1e-9
     # the exchange on its own (outside the timed region): rows, bytes per link, time
     x = rec["exchange"]
     assert x["ms_alone_per_layer"] > 0 and x["rows_received_per_rank_per_layer"] > 0
@@ -110,6 +141,7 @@ def test_bench_falls_back_to_the_one_pass_halo_exchange():
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert "overlapped" not in rec["config"]["exchange"] and "all-to-all of halo rows" in rec["config"]["exchange"]
     assert "injected failure" in out.stderr and rec["value"] > 0
+    assert rec["exchange_fallback"] is True                     # in the line, not only on stderr
 
 
 def test_bench_single_gpu_line_has_the_contract_fields():
@@ -130,9 +162,15 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     rl = rec["roofline"]
     assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
     assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9 and rl["launches_timed"] == 8
+    assert rl["traffic"] is None or rl["traffic_source"]          # never a byte count without saying where it is from
+    assert rl["kernel"].startswith("spmm_kernel<f16,8,8>") and rec["backend"] is None and rec["world_size"] == 1
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "edges/s"
     assert rec["value"] > cb["value"]
+    # the reference's own CPU formulation (torch.mm + torch.spmm) beside the port, at one thread and at the granted cores
+    rf = cb["reference_formulation"]
+    assert "torch.sparse.mm" in rf["formulation"] and rf["threads_1"]["threads"] == 1
+    assert rf["threads_1"]["edges_per_s"] > 0 and rf["threads_granted"]["edges_per_s"] > 0
 
 
 _RCCL_SELF = r'''
@@ -156,7 +194,7 @@ far = graphs.uniform_graph(n, 9000, seed=13, device=dev)
 far_col = (far.col.long() % k).int()
 A_far = ops.Csr(far.rowptr, far_col, far.val, k)
 plan = D.HaloPlan(bounds=[0, n], rank=0, col_compact=A_own.col, send_rows=send_rows, send_counts=[k], recv_counts=[k],
-                  n_own=n)
+                  n_own=n, send_rows32=send_rows.int())
 backend = D.hip_backend()
 H = ops.xw_dense(X, Wt)
 part = ops.spmm_acc(A_own, H, partial_out=True)
@@ -173,7 +211,9 @@ rows = torch.cat([rows_o, rows_f]); cols = torch.cat([A_own.col.long(), A_far.co
 vals = torch.cat([A_own.val, A_far.val])
 order = torch.argsort(rows * (n + k) + cols)
 A_all = ops.Csr(rp.int(), cols[order].int(), vals[order], n + k)
-plan2 = D.HaloPlan(bounds=[0, n], rank=0, col_compact=A_all.col, send_rows=send_rows, send_counts=[k], recv_counts=[k], n_own=n)
+plan2 = D.HaloPlan(bounds=[0, n], rank=0, col_compact=A_all.col, send_rows=send_rows, send_counts=[k], recv_counts=[k], n_own=n,
+                   send_rows32=send_rows.int())
+assert torch.equal(ops.pack_rows(H, send_rows.int()), H.index_select(0, send_rows))        # the pack kernel itself
 got2 = D.layer_halo(backend, A_all, X, Wt, True, plan2)
 table = torch.cat([H, H.index_select(0, send_rows)])
 assert torch.equal(got2, ops.spmm(A_all, table, relu=True))
@@ -184,6 +224,7 @@ assert auto.n_own == n and auto.recv_counts == [0] and auto.send_counts == [0]
 assert torch.equal(auto.col_compact, A_own.col)
 got3 = D.layer_allgather(backend, A_own, X, Wt, True, [0, n])
 assert torch.equal(got3, ops.spmm(A_own, H, relu=True))
+assert torch.equal(D.layer_allgather(backend, A_own, X, Wt, True, [0, n], direct=True), got3)
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("rccl-self-ok")

@@ -33,7 +33,7 @@ def test_kat_4x4(oracle):
 def test_csim_log_citeseer(oracle):
     """HALF build, SPMM_BLOCK=4, FADD latency 4: 40 of the 42 logged values are reproduced to the printed digit; the
     other two -- (row 0, col 10) and (row 31, col 18), exactly these, one binary16 ulp each, the model's magnitude above
-    the log's -- are printed by no setting or reading of the checked-in source (tools/csim_residual.py enumerates
+    the log's -- are printed by no setting or reading of the checked-in source (tests/csim_residual.py enumerates
     them; profiles/r02_csim_residual.txt), so the log comes from a kernel revision that differs from the source there.
     Every other (SPMM_BLOCK, latency, thread) setting reproduces fewer."""
     d = load("citeseer")
