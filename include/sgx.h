@@ -348,7 +348,7 @@ int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void 
 int sgx_pack_rows(int dtype, int64_t n_rows, int n_feat, const void *src, int64_t ld_src, const int32_t *row_index,
                   void *dst, int64_t ld_dst, void *stream);
 
-/* A plain streaming copy (16 bytes per lane, non-temporal), the kernel the attainable HBM rate of a device is
+/* A plain streaming copy (16 bytes per lane, non-temporal, each workgroup on a contiguous chunk), the kernel the attainable HBM rate of a device is
  * measured with next to the nominal 8 TB/s (bench.py reports it as roofline.stream_copy_GBps_this_device).
  * bytes must be a multiple of 16, both pointers 16-byte aligned. */
 int sgx_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);

@@ -68,20 +68,24 @@ __global__ __launch_bounds__(kBlock) void relu_mask_kernel(const TO *__restrict_
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// 16 bytes per lane, 4 loads in flight per lane, grid-stride: the plain streaming copy the HBM roof is quoted on
+// The plain streaming copy the attainable HBM rate is quoted on: 16 bytes per lane, non-temporal both ways, 4 loads in
+// flight per lane, every workgroup on a contiguous chunk of its own.  The best of the forms swept on these boxes
+// (tools/micro/copy_sweep.hip, profiles/r02_copy_sweep.txt: 5.5-5.6 TB/s read + write at every grid size; the
+// grid-stride form this replaces 4.3-5.1 TB/s depending on the grid, hipMemcpy device-to-device 5.1).
 __global__ __launch_bounds__(kBlock) void stream_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, int64_t n16)
 {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    const int64_t per_block = (n16 + gridDim.x - 1) / gridDim.x;
+    int64_t i = (int64_t)blockIdx.x * per_block + threadIdx.x;
+    const int64_t end = (int64_t)(blockIdx.x + 1) * per_block < n16 ? (int64_t)(blockIdx.x + 1) * per_block : n16;
+    for (; i + 3 * kBlock < end; i += 4 * kBlock) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + kBlock);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * kBlock), d = __builtin_nontemporal_load(src + i + 3 * kBlock);
         __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        __builtin_nontemporal_store(b, dst + i + kBlock);
+        __builtin_nontemporal_store(c, dst + i + 2 * kBlock);
+        __builtin_nontemporal_store(d, dst + i + 3 * kBlock);
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    for (; i < end; i += kBlock) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 // rows of row_bytes bytes from pitch src_pitch to pitch dst_pitch (a multiple of 16, dst 16-byte aligned): one lane per
@@ -235,7 +239,7 @@ extern "C" int sgx_stream_copy(void *dst, const void *src, int64_t bytes, void *
     if (bytes == 0) return SGX_OK;
     if (!dst || !src) return SGX_ERR_NULL;
     if ((uintptr_t)dst % 16 != 0 || (uintptr_t)src % 16 != 0) return SGX_ERR_ALIGN;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(kBlock), 0, (hipStream_t)stream, (const u32x4 *)src,
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(kBlock), 0, (hipStream_t)stream, (const u32x4 *)src,
                        (u32x4 *)dst, bytes / 16);
     SGX_LAUNCH_CHECK();
     return SGX_OK;

@@ -63,6 +63,25 @@ def rmat_graph(scale, n_edges, a=0.57, b=0.19, c=0.19, seed=12345, device="cuda"
     return _finish(row, col, n, dtype, self_loops, normalize)
 
 
+def rmat_graph_n(n, n_edges, a=0.57, b=0.19, c=0.19, seed=12345, device="cuda", dtype=torch.float16, self_loops=True,
+                 normalize=True):
+    """R-MAT on any number of nodes (the Reddit / ogbn-products / ogbn-arxiv shapes are not powers of two): generated
+    on 2^ceil(log2 n) ids, every id folded onto [0, n) by id * n >> scale, which keeps neighbouring ids -- and with
+    them the skew of the degree distribution -- together."""
+    scale = max(1, (n - 1).bit_length())
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    row = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    col = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        u = torch.rand(n_edges, generator=g, device=device)
+        row = row * 2 + (u >= a + b).to(torch.int64)
+        col = col * 2 + (((u >= a) & (u < a + b)) | (u >= a + b + c)).to(torch.int64)
+    row = (row * n) >> scale
+    col = (col * n) >> scale
+    return _finish(row, col, n, dtype, self_loops, normalize)
+
+
 def block_local_graph(n, n_edges, n_blocks, p_local=0.9, seed=12345, device="cuda", dtype=torch.float16):
     """Uniform graph whose edges stay inside the row's block (of n/n_blocks nodes) with
     probability p_local: the partition-friendly stand-in used for the multi-GPU halo path."""

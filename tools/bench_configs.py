@@ -3,7 +3,11 @@
 dataset is not in the container) on one GPU and prints one JSON line per configuration:
 per-stage times from hipEvents, edges/s, algorithmic GB/s of the aggregation stage.
 
-    python tools/bench_configs.py [--only c1,c3] [--iters 20]
+    python tools/bench_configs.py [--only c1,c3] [--iters 20] [--gen uniform|rmat|both] [--pmc-launches K]
+
+--gen: the generator of the c3 / c4 / c5 graphs (uniform: row, col ~ U[0, n); rmat: R-MAT .57/.19/.19/.05 folded onto
+the shape's node count -- the real graphs are heavy-tailed).  --pmc-launches K: only K launches of each configuration's
+aggregation kernel and nothing else, for a `rocprofv3 --pmc` pass (tools/pmc_passes.sh; summary: tools/configs_pmc.py).
 
 c1  molecule_gcn: the 188-graph MUTAG batch (3371 nodes, 7442 edges), 7 -> 64 -> 64, sparse X then dense X
 c2  Cora: the reference's cora_{adj,feat,weights}.txt, 1433 -> 64 (sparse X, ReLU) -> 7 (dense X)
@@ -64,6 +68,13 @@ def report(name, A, stages, extra):
     print(json.dumps(rec), flush=True)
 
 
+PMC_LAUNCHES = 0
+
+
+def make_graph(gen_name, n, n_edges, seed, **kw):
+    return (graphs.rmat_graph_n if gen_name == "rmat" else graphs.uniform_graph)(n, n_edges, seed=seed, **kw)
+
+
 def gcn_two_layer(name, A, X, W1t, W2t, iters, small=False):
     hid, out = W1t.shape[0], W2t.shape[0]
     D1 = torch.empty((A.n_rows, hid), dtype=torch.float16, device=dev)
@@ -71,6 +82,15 @@ def gcn_two_layer(name, A, X, W1t, W2t, iters, small=False):
     A.plan
     if isinstance(X, ops.Csr):
         X.plan
+    if PMC_LAUNCHES:
+        Hp = torch.empty((A.n_cols, hid), dtype=torch.float16, device=dev).normal_()
+        for _ in range(PMC_LAUNCHES):
+            ops.spmm(A, Hp, relu=True, out=D1)
+        torch.cuda.synchronize()
+        deg = A.rowptr.diff()
+        print(json.dumps({"config": name, "pmc_launches": PMC_LAUNCHES, "nodes": A.n_rows, "edges": A.nnz, "hidden": hid,
+                          "max_degree": int(deg.max()), "long_rows": A.plan.long_rows, "reordered": A.plan.reordered}), flush=True)
+        return
 
     def fwd():
         ops.layer_forward(A, X, W1t, relu=True, out=D1)
@@ -93,6 +113,7 @@ def gcn_two_layer(name, A, X, W1t, W2t, iters, small=False):
              "edges_per_s_2layer": 2 * A.nnz / (t_fwd * 1e-3),
              "agg1_algorithmic_GBps": b_alg1 / (t_agg1 * 1e-3) / 1e9,
              "agg1_frac_of_8TBps": b_alg1 / (t_agg1 * 1e-3) / 8e12,
+             "agg1_algorithmic_bytes": b_alg1, "max_degree": int(A.rowptr.diff().max()),
              "plan": {"long_rows": A.plan.long_rows, "reordered": A.plan.reordered,
                       "natural_utilization": round(A.plan.natural_utilization, 3)}}
     stages = {"ms_forward_2layer": t_fwd, "ms_xw1": t_xw1, "ms_agg1": t_agg1, "ms_xw2": t_xw2, "ms_agg2": t_agg2}
@@ -112,7 +133,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="c1,c2,c3,c4,c5")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--gen", default="uniform", choices=("uniform", "rmat", "both"))
+    ap.add_argument("--pmc-launches", type=int, default=0)
     args = ap.parse_args()
+    global PMC_LAUNCHES
+    PMC_LAUNCHES = args.pmc_launches
+    gens = ("uniform", "rmat") if args.gen == "both" else (args.gen,)
     want = set(args.only.split(","))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1)
@@ -149,28 +175,44 @@ def main():
         gcn_two_layer("c2 Cora (reference matrices)", A, X, torch.as_tensor(d["Wt"], device=dev).half(),
                       torch.as_tensor(np.ascontiguousarray(w2.T), device=dev).half(), 200, small=True)
 
-    if "c3" in want:
+    for g_name in (gens if "c3" in want else ()):
         n = 232_965
-        A = graphs.uniform_graph(n, 114_600_000, seed=3)
+        A = make_graph(g_name, n, 114_600_000, 3)
         X = torch.rand((n, 602), generator=gen, device=dev).half()
-        gcn_two_layer("c3 Reddit shape", A, X, rand_w(128, 602, gen), rand_w(41, 128, gen), args.iters)
+        gcn_two_layer(f"c3 Reddit shape ({g_name})", A, X, rand_w(128, 602, gen), rand_w(41, 128, gen), args.iters)
         del A, X
+        torch.cuda.empty_cache()
 
-    if "c4" in want:
+    for g_name in (gens if "c4" in want else ()):
         n = 2_449_029
-        A = graphs.uniform_graph(n, 123_700_000, seed=4)
+        A = make_graph(g_name, n, 123_700_000, 4)
         X = torch.rand((n, 100), generator=gen, device=dev).half()
-        gcn_two_layer("c4 ogbn-products shape (1 GPU)", A, X, rand_w(256, 100, gen), rand_w(47, 256, gen), args.iters)
+        gcn_two_layer(f"c4 ogbn-products shape, 1 GPU ({g_name})", A, X, rand_w(256, 100, gen), rand_w(47, 256, gen), args.iters)
         del A, X
+        torch.cuda.empty_cache()
 
-    if "c5" in want:
+    for g_name in (gens if "c5" in want else ()):
         n, P = 169_343, 256
-        A = graphs.uniform_graph(n, 2_330_000, seed=5)
+        A = make_graph(g_name, n, 2_330_000, 5)
         X = torch.rand((n, 128), generator=gen, device=dev).half()
         Wt = rand_w(P, 128, gen)
         att = ((torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.3).half()
         D = torch.empty((n, P), dtype=torch.float16, device=dev)
         A.plan
+        if PMC_LAUNCHES:
+            Wh = ops.xw_dense(X, Wt)
+            att8 = ((torch.rand(2 * P, generator=gen, device=dev) * 2 - 1) * 0.3).half()
+            for _ in range(PMC_LAUNCHES):
+                ops.gat_aggregate(A, Wh, att, relu=True, out=D)
+            for _ in range(PMC_LAUNCHES):
+                ops.gat_aggregate(A, Wh, att8, relu=True, heads=8, out=D)
+            for _ in range(PMC_LAUNCHES):
+                ops.spmm(A, Wh, relu=True, out=D)
+            torch.cuda.synchronize()
+            print(json.dumps({"config": f"c5 ogbn-arxiv shape GAT ({g_name})", "pmc_launches": PMC_LAUNCHES, "nodes": n,
+                              "edges": A.nnz, "width": P, "max_degree": int(A.rowptr.diff().max()),
+                              "long_rows": A.gat_plan.long_rows}), flush=True)
+            continue
         t_layer = timed(lambda: ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, out=D), 100)
         Wh = ops.xw_dense(X, Wt)
         t_gat = timed(lambda: ops.gat_aggregate(A, Wh, att, relu=True), 100)
@@ -183,14 +225,16 @@ def main():
         Wh32, G32 = Wh.float(), torch.randn((n, P), generator=gen, device=dev)
         t_bwd = timed(lambda: ops.gat_backward_edges(A, E_, S_, G32, Wh32), 50)
         b_alg = A.nnz * (6 + 8 + P * 2) + (n + 1) * 4 + n * P * 2
-        report("c5 ogbn-arxiv shape GAT", A,
+        report(f"c5 ogbn-arxiv shape GAT ({g_name})", A,
                {"ms_layer": t_layer, "ms_gat_aggregate": t_gat, "ms_gcn_aggregate_same_shape": t_gcn,
                 "ms_layer_8_heads": t_layer8, "ms_gat_aggregate_8_heads": t_gat8, "ms_gat_backward_edge_pass_fp32": t_bwd},
                {"f_in": 128, "width": P, "heads": "ms_layer: 8 x 32 as one 256-wide single-softmax head (reference semantics, "
                 "nheads only widens W); ms_layer_8_heads: 8 independent softmaxes of 32 columns",
-                "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9})
+                "edges_per_s_layer": A.nnz / (t_layer * 1e-3), "gat_algorithmic_GBps": b_alg / (t_gat * 1e-3) / 1e9,
+                "gat_algorithmic_bytes": b_alg, "max_degree": int(A.rowptr.diff().max()),
+                "gat_over_plain_aggregate": t_gat / t_gcn, "long_rows": A.gat_plan.long_rows})
 
-    if "c5" in want:
+    if "c5" in want and not PMC_LAUNCHES:
         # the SGRACE library's own setting: float32 buffers, 8-bit quantised arithmetic (the reference's board
         # configs ship with fake_quantization = hardware_quantize = 1, w_qbits = 8)
         from sgracex1_amd import quant
@@ -210,7 +254,7 @@ def main():
         report("c5 in the SGRACE library's setting (float32 buffers, w_qbits 8)", A32, rec, {"f_in": 128, "width": P})
         del A32, X32, D32
 
-    if "c5" in want:
+    if "c5" in want and not PMC_LAUNCHES:
         # the same layer on a power-law graph (R-MAT, 2^18 nodes): hub rows take the split path of the plan
         n, P = 1 << 18, 256
         A = graphs.rmat_graph(18, 2_330_000, seed=6)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Counter passes of one command on the GPU box, one rocprofv3 --pmc run per counter group (never combined with
 # trace domains other than the kernel trace):  tools/pmc_passes.sh <out-dir> -- <program> [args...]
-# Groups: SQ occupancy/wait split, SQ instruction mix + LDS conflicts, FETCH_SIZE, WRITE_SIZE, L2 hit/miss.
+# Groups: 1 SQ occupancy/wait split, 2 SQ instruction mix + LDS conflicts, 3 FETCH_SIZE, 4 WRITE_SIZE, 5 L2 hit/miss,
+# 6 clocks / TA busy.  PMC_ONLY="3 4 5" restricts the run to those groups.
 set -o pipefail
 out=$1; shift; shift
 mkdir -p "$out"
@@ -11,6 +12,7 @@ for group in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
              "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
              "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE TA_BUSY_avr"; do
     i=$((i + 1))
+    if [ -n "$PMC_ONLY" ] && ! echo " $PMC_ONLY " | grep -q " $i "; then continue; fi      # PMC_ONLY="3 4 5": these groups only
     rocprofv3 --pmc $group --output-format csv -d "$out/pass$i" -- "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i ($group) failed"; tail -5 "$out/pass$i.log"; }
 done
 python3 - "$out" <<'PY'
