@@ -16,6 +16,8 @@
 // pass over Wh for the column means); without it such rows produce 0.
 #include "sgx_device.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 namespace {
@@ -515,6 +517,8 @@ struct GatArgs {
     const float *fill;
     int uniform_n;             // the N of the uniform softmax a dead row gets (S = 1/N): n_cols, or all nodes of a partitioned graph
     float out_scale;           // deq_o of the quantised layer on fp32 outputs (0 = off)
+    const sgx_plan *plan_any;  // the caller's plan, long rows or not (two-stage form: it tells the stored-entry count)
+    float *two_stage;          // scratch of the two-stage form: weights [nnz * heads], then dead-row flags [n_rows bytes]
     const sgx_plan *plan;      // long rows -> split path
     float *split;              // scratch of the split path, behind the scores / column means
     int vec_ok, vec_store;
@@ -522,8 +526,12 @@ struct GatArgs {
 };
 
 template <typename T, int VEC, int LPR>
+int gat_two_stage(const GatArgs &a);
+
+template <typename T, int VEC, int LPR>
 int gat_launch_one(const GatArgs &a)
 {
+    if (a.two_stage) return gat_two_stage<T, VEC, LPR>(a);
     const int rows_per_block = (64 / LPR) * (kBlock / 64);
     const unsigned grid = (unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block);
     const unsigned grid_s = (unsigned)((a.n_cols + rows_per_block - 1) / rows_per_block);
@@ -609,6 +617,915 @@ int gat_launch_one(const GatArgs &a)
     return SGX_OK;
 }
 
+// =======================================================================================
+// Two-stage form (used whenever a plan tells the stored-entry count): the softmax weights first, then a plain
+// weighted aggregation.
+//   stage A (edge work only: 4-byte score gathers, no rows of Wh): per row the maximum and the sum of its live
+//     edges' scores, then alpha_e = exp(x_e - m) / l for every stored edge -- the reference's `attention` matrix on
+//     the stored entries (SG.py:649-653), which is also the S output.  Rows over the plan's cut go through its
+//     tasks (per-task states merged in task order).
+//   stage B: D = act(sum_e alpha_e Wh[col_e]) -- the A.H aggregation with fp32 edge weights: the same gather loop,
+//     long-row tasks and fixed-order finalize as spmm_csr.hip.  With several heads a lane reads the weight of ITS
+//     head for each edge (8 weights per edge lie in one 32-byte piece); each neighbour row is still gathered once.
+// Why: the one-pass kernels above chain three dependent memory latencies per piece (column -> score -> rows) and carry a
+// softmax state through every step; on the ogbn-arxiv shape they take 0.27 ms (8 heads 0.41) against 0.18 ms for the
+// plain aggregate of the same rows, and hub rows multiply that (R-MAT arxiv shape: 8 heads 1.08 ms).  Stage A moves
+// ~14 bytes per edge, stage B is the plain aggregate.
+// =======================================================================================
+constexpr int kAlphaLanes = 8;             // lanes per row in stage A (8 rows per wavefront)
+
+__device__ __forceinline__ void online_add(float &m, float &l, float x)
+{
+    if (x > m) { l = l * rescale_factor(m, x) + 1.0f; m = x; }
+    else l += expf(x - m);
+}
+
+// short rows: (max, sum) per head, then the weights; E optional; dead[r] = 1 when the row has no live edge.
+// 8 lanes per row split its edges; a row over kCoopEdges8 edges (up to the plan's cut) is taken by the whole wavefront.
+constexpr int kCoopEdges8 = 64;
+
+template <typename T, int HB>
+__global__ __launch_bounds__(kBlock) void gat_alpha_rows_kernel(
+    int n_rows, int n_heads, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const T *__restrict__ val,
+    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, int long_threshold,
+    float *__restrict__ W, float *__restrict__ E, unsigned char *__restrict__ dead)
+{
+    constexpr int GL = kAlphaLanes;
+    const int lane = threadIdx.x & 63, sub = lane % GL, grp = lane / GL;
+    const int64_t r_first = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / GL);
+    const int64_t r = r_first + grp;
+    int e0 = 0, e1 = 0;
+    bool live_row = r < n_rows;
+    if (live_row) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    if (live_row && long_threshold > 0 && e1 - e0 > long_threshold) { live_row = false; e1 = e0; }   // the tasks own it
+    const int coop_deg = e1 - e0 > kCoopEdges8 ? e1 - e0 : 0;
+    const int ce0 = e0;
+    if (coop_deg) { live_row = false; e1 = e0; }                                 // taken by the whole wavefront below
+    for (int hb0 = 0; hb0 < n_heads; hb0 += HB) {
+        float si[HB], m[HB], l[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) { si[h] = live_row ? s1[r * n_heads + hb0 + h] : 0.0f; m[h] = -INFINITY; l[h] = 0.0f; }
+        for (int idx = e0 + sub; idx < e1; idx += GL) {
+            const int c = col[idx];
+            const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                const float x = leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha);
+                if (E) E[(int64_t)idx * n_heads + hb0 + h] = x;
+                if (pos) online_add(m[h], l[h], x);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < GL; off <<= 1) {
+#pragma unroll
+            for (int h = 0; h < HB; ++h) softmax_merge(m[h], l[h], __shfl_xor(m[h], off), __shfl_xor(l[h], off));
+        }
+        for (int idx = e0 + sub; idx < e1; idx += GL) {
+            const int c = col[idx];
+            const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                float w = 0.0f;
+                if (pos && l[h] > 0.0f) w = expf(leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha) - m[h]) / l[h];
+                W[(int64_t)idx * n_heads + hb0 + h] = w;
+            }
+        }
+        if (hb0 == 0 && live_row && sub == 0) dead[r] = l[0] > 0.0f ? 0 : 1;      // the mask does not depend on the head
+    }
+    for (int g = 0; g < 64 / GL; ++g) {
+        const int dg = __shfl(coop_deg, g * GL);
+        if (dg == 0) continue;                                                     // wave-uniform
+        const int ge0 = __shfl(ce0, g * GL), ge1 = ge0 + dg;
+        const int64_t gr = r_first + g;
+        for (int hb0 = 0; hb0 < n_heads; hb0 += HB) {
+            float si[HB], m[HB], l[HB];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) { si[h] = s1[gr * n_heads + hb0 + h]; m[h] = -INFINITY; l[h] = 0.0f; }
+            for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+                const int c = col[idx];
+                const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float x = leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha);
+                    if (E) E[(int64_t)idx * n_heads + hb0 + h] = x;
+                    if (pos) online_add(m[h], l[h], x);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                for (int h = 0; h < HB; ++h) softmax_merge(m[h], l[h], __shfl_xor(m[h], off), __shfl_xor(l[h], off));
+            }
+            for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+                const int c = col[idx];
+                const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    float w = 0.0f;
+                    if (pos && l[h] > 0.0f) w = expf(leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha) - m[h]) / l[h];
+                    W[(int64_t)idx * n_heads + hb0 + h] = w;
+                }
+            }
+            if (hb0 == 0 && lane == 0) dead[gr] = l[0] > 0.0f ? 0 : 1;
+        }
+    }
+}
+
+// One head, rows up to 512 edges (every row when the plan cuts at 256): the row's entries live in registers -- 8 per
+// lane -- so a row costs two memory round trips (columns and values, then the scores of those columns) whatever its
+// length: 8 lanes per row for rows of up to 64 edges (8 rows per wavefront together), the whole wavefront for one row
+// of 65..512 edges at a time.  Out-of-range buffer offsets stand in for branches.  Longer rows (a caller's plan with a
+// larger cut) take two walks over memory.
+template <typename T, int STRIDE>
+__device__ __forceinline__ void alpha_row_in_registers(
+    bool active, int e0, int deg, int first, int kmax, float si, float alpha, const __amdgpu_buffer_rsrc_t &col_rsrc,
+    const __amdgpu_buffer_rsrc_t &val_rsrc, const __amdgpu_buffer_rsrc_t &s2_rsrc, const __amdgpu_buffer_rsrc_t &w_rsrc,
+    const __amdgpu_buffer_rsrc_t &e_rsrc, bool want_e, float &l_out)
+{
+    float x[8];
+    unsigned pos = 0u;
+    unsigned c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= kmax) break;                                                      // wave-uniform
+        const bool ok = active && first + k * STRIDE < deg;
+        const unsigned off = ok ? (unsigned)(e0 + first + k * STRIDE) * 4u : kOOB;
+        c[k] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
+        float v;
+        if constexpr (sizeof(T) == 2) v = (float)__builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0));
+        else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
+        pos |= (ok && v > 0.0f) ? (1u << k) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= kmax) break;
+        const bool ok = active && first + k * STRIDE < deg;
+        x[k] = leaky(si + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s2_rsrc, ok ? c[k] * 4u : kOOB, 0, 0)), alpha);
+        if (want_e) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[k]), e_rsrc,
+                                                          ok ? (unsigned)(e0 + first + k * STRIDE) * 4u : kOOB, 0, 0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= kmax) break;
+        m = (pos >> k) & 1u ? fmaxf(m, x[k]) : m;
+    }
+#pragma unroll
+    for (int off = 1; off < STRIDE; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float l = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= kmax) break;
+        x[k] = (pos >> k) & 1u ? expf(x[k] - m) : 0.0f;
+        l += x[k];
+    }
+#pragma unroll
+    for (int off = 1; off < STRIDE; off <<= 1) l += __shfl_xor(l, off);
+    const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k >= kmax) break;
+        const bool ok = active && first + k * STRIDE < deg;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[k] * inv_l), w_rsrc,
+                                              ok ? (unsigned)(e0 + first + k * STRIDE) * 4u : kOOB, 0, 0);
+    }
+    l_out = l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_alpha_rows_1head_kernel(
+    int n_rows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const T *__restrict__ val,
+    unsigned nnz_bytes_col, const float *__restrict__ s1, const float *__restrict__ s2, unsigned s_bytes, float alpha,
+    int long_threshold, float *__restrict__ W, float *__restrict__ E, unsigned char *__restrict__ dead)
+{
+    constexpr int GL = 8;
+    const int lane = threadIdx.x & 63, sub = lane % GL, grp = lane / GL;
+    const int64_t r_first = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / GL);
+    const int64_t r = r_first + grp;
+    int e0 = 0, e1 = 0;
+    if (r < n_rows) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    const bool tasked = long_threshold > 0 && e1 - e0 > long_threshold;           // the tasks own it
+    const int deg = tasked ? 0 : e1 - e0;
+    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(col), 0, nnz_bytes_col, 0x00020000);
+    const __amdgpu_buffer_rsrc_t val_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(val), 0, (unsigned)(nnz_bytes_col / 4 * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t s2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s2), 0, s_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(W, 0, nnz_bytes_col, 0x00020000);
+    const __amdgpu_buffer_rsrc_t e_rsrc = __builtin_amdgcn_make_buffer_rsrc(E ? E : W, 0, nnz_bytes_col, 0x00020000);
+
+    // rows of up to 64 edges: 8 lanes each, all 8 rows of the wavefront together
+    const bool small = r < n_rows && !tasked && deg <= 64;
+    int nm = small ? deg : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nm = max(nm, __shfl_xor(nm, off));
+    nm = __builtin_amdgcn_readfirstlane(nm);
+    {
+        float l = 0.0f;
+        const float si = small ? s1[r] : 0.0f;
+        alpha_row_in_registers<T, GL>(small, e0, deg, sub, (nm + GL - 1) / GL, si, alpha, col_rsrc, val_rsrc, s2_rsrc, w_rsrc, e_rsrc,
+                                      E != nullptr, l);
+        if (small && sub == 0) dead[r] = l > 0.0f ? 0 : 1;
+    }
+    // rows of 65..512 edges: the whole wavefront, one row at a time
+    const int mid_deg = (r < n_rows && !tasked && deg > 64 && deg <= 512) ? deg : 0;
+    const int big_deg = (r < n_rows && !tasked && deg > 512) ? deg : 0;
+    for (int g = 0; g < 64 / GL; ++g) {
+        const int dg = __shfl(mid_deg, g * GL);
+        if (dg == 0) continue;                                                     // wave-uniform
+        const int ge0 = __shfl(e0, g * GL);
+        float l = 0.0f;
+        alpha_row_in_registers<T, 64>(true, ge0, dg, lane, (dg + 63) / 64, s1[r_first + g], alpha, col_rsrc, val_rsrc, s2_rsrc, w_rsrc,
+                                      e_rsrc, E != nullptr, l);
+        if (lane == 0) dead[r_first + g] = l > 0.0f ? 0 : 1;
+    }
+    // rows over 512 edges that the plan did not cut: two walks over memory, whole wavefront
+    for (int g = 0; g < 64 / GL; ++g) {
+        const int dg = __shfl(big_deg, g * GL);
+        if (dg == 0) continue;
+        const int ge0 = __shfl(e0, g * GL), ge1 = ge0 + dg;
+        const int64_t gr = r_first + g;
+        const float si = s1[gr];
+        float m = -INFINITY, l = 0.0f;
+        for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+            const float xk = leaky(si + s2[col[idx]], alpha);
+            if (E) E[idx] = xk;
+            if (Elem<T>::to_f32(val[idx]) > 0.0f) m = fmaxf(m, xk);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        for (int idx = ge0 + lane; idx < ge1; idx += 64)
+            if (Elem<T>::to_f32(val[idx]) > 0.0f) l += expf(leaky(si + s2[col[idx]], alpha) - m);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) l += __shfl_xor(l, off);
+        for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+            float w = 0.0f;
+            if (Elem<T>::to_f32(val[idx]) > 0.0f && l > 0.0f) w = expf(leaky(si + s2[col[idx]], alpha) - m) / l;
+            W[idx] = w;
+        }
+        if (lane == 0) dead[gr] = l > 0.0f ? 0 : 1;
+    }
+}
+
+// the scores of heads [hb0, hb0 + 8) of node c: two 16-byte loads when the row of 8 floats is aligned (n_heads a
+// multiple of 8 and an aligned table), else element loads; entries past n_heads are 0
+__device__ __forceinline__ void load_scores8(const float *__restrict__ s2, int64_t c, int n_heads, int hb0, bool vec, float *out)
+{
+    if (vec) {
+        const float4 a = *reinterpret_cast<const float4 *>(s2 + c * n_heads + hb0);
+        const float4 b = *reinterpret_cast<const float4 *>(s2 + c * n_heads + hb0 + 4);
+        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = hb0 + k < n_heads ? s2[c * n_heads + hb0 + k] : 0.0f;
+    }
+}
+__device__ __forceinline__ void store8(float *__restrict__ dst, int64_t idx, int n_heads, int hb0, bool vec, const float *v)
+{
+    if (vec) {
+        *reinterpret_cast<float4 *>(dst + idx * n_heads + hb0) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4 *>(dst + idx * n_heads + hb0 + 4) = float4{v[4], v[5], v[6], v[7]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (hb0 + k < n_heads) dst[idx * n_heads + hb0 + k] = v[k];
+    }
+}
+
+// short rows, several heads: one lane per (row, head), LH = heads rounded up to a power of two lanes per row.  The
+// lanes of a row read the same column indices and one contiguous piece of the score / weight rows (LH x 4 bytes).
+// A row of up to kAloneEdges edges is taken in ONE pass with everything in registers: its column indices, then its
+// scores, are requested together (out-of-range offsets past the row's end: no branches, no access), so a row costs
+// two memory round trips whatever its length; maximum, sum and weights follow from the registers.  Longer rows (up to
+// the plan's cut) are taken by the whole wavefront one at a time -- a lane per edge, 8 heads in its registers -- with
+// the maximum and the sum folded across lanes separately (a max / an add per shuffle instead of a softmax merge).
+constexpr int kAloneEdges = 32;
+
+template <typename T, int LH>
+__global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
+    int n_rows, int n_heads, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const T *__restrict__ val,
+    unsigned nnz_bytes_col, const float *__restrict__ s1, const float *__restrict__ s2, unsigned s_bytes, float alpha,
+    int long_threshold, float *__restrict__ W, float *__restrict__ E, unsigned char *__restrict__ dead)
+{
+    constexpr int RPW = 64 / LH;
+    constexpr int KB = kAloneEdges;
+    const int lane = threadIdx.x & 63, h = lane % LH, grp = lane / LH;
+    const int64_t r_first = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW;
+    const int64_t r = r_first + grp;
+    const bool head_ok = h < n_heads;
+    int e0 = 0, e1 = 0;
+    if (r < n_rows) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
+    const bool tasked = long_threshold > 0 && e1 - e0 > long_threshold;           // the tasks own it
+    if (tasked) e1 = e0;
+    const int deg = e1 - e0;
+    const bool alone = r < n_rows && !tasked && deg <= KB;
+    const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(col), 0, nnz_bytes_col, 0x00020000);
+    const __amdgpu_buffer_rsrc_t val_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(val), 0, (unsigned)(nnz_bytes_col / 4 * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t s2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s2), 0, s_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(W, 0, nnz_bytes_col * (unsigned)n_heads, 0x00020000);
+    const __amdgpu_buffer_rsrc_t e_rsrc = __builtin_amdgcn_make_buffer_rsrc(E ? E : W, 0, nnz_bytes_col * (unsigned)n_heads, 0x00020000);
+
+    int nm = alone ? deg : 0;                                                    // the longest such row of the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nm = max(nm, __shfl_xor(nm, off));
+    nm = __builtin_amdgcn_readfirstlane(nm);
+    if (nm > 0) {
+        const float si = (alone && head_ok) ? s1[r * n_heads + h] : 0.0f;
+        float x[KB];
+        unsigned pos = 0u;
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 8) {
+            if (k0 >= nm) break;
+            unsigned c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = alone && head_ok && k0 + k < deg;
+                const unsigned off = ok ? (unsigned)(e0 + k0 + k) * 4u : kOOB;
+                c[k] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
+                float v;
+                if constexpr (sizeof(T) == 2) {
+                    const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0);
+                    v = (float)__builtin_bit_cast(T, hb);
+                } else {
+                    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
+                }
+                pos |= (ok && v > 0.0f) ? (1u << (k0 + k)) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = alone && head_ok && k0 + k < deg;
+                const float sj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                     s2_rsrc, ok ? (c[k] * (unsigned)n_heads + (unsigned)h) * 4u : kOOB, 0, 0));
+                x[k0 + k] = leaky(si + sj, alpha);
+                if (E) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[k0 + k]), e_rsrc,
+                                                             ok ? ((unsigned)(e0 + k0 + k) * (unsigned)n_heads + (unsigned)h) * 4u : kOOB, 0, 0);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 8) {
+            if (k0 >= nm) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = (pos >> (k0 + k)) & 1u ? fmaxf(m, x[k0 + k]) : m;
+        }
+        float l = 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 8) {
+            if (k0 >= nm) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float p = (pos >> (k0 + k)) & 1u ? expf(x[k0 + k] - m) : 0.0f;
+                x[k0 + k] = p;
+                l += p;
+            }
+        }
+        const float inv_l = l > 0.0f ? 1.0f / l : 0.0f;
+#pragma unroll
+        for (int k0 = 0; k0 < KB; k0 += 8) {
+            if (k0 >= nm) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = alone && head_ok && k0 + k < deg;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[k0 + k] * inv_l), w_rsrc,
+                                                      ok ? ((unsigned)(e0 + k0 + k) * (unsigned)n_heads + (unsigned)h) * 4u : kOOB, 0, 0);
+            }
+        }
+        if (alone && h == 0) dead[r] = l > 0.0f ? 0 : 1;
+    }
+
+    // the longer rows of this wavefront, one at a time with every lane: a lane per edge, the heads (8 at a time) in its
+    // registers; maximum first, then the sum of exp(x - max), then the weights
+    const int coop_deg = (!tasked && deg > KB) ? deg : 0;
+    const bool vec8 = n_heads % 8 == 0 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(E)) % 16 == 0;
+    for (int g = 0; g < RPW; ++g) {
+        const int dg = __shfl(coop_deg, g * LH);
+        if (dg == 0) continue;                                                     // wave-uniform
+        const int ge0 = __shfl(e0, g * LH), ge1 = ge0 + dg;
+        const int64_t gr = r_first + g;
+        if (dg <= 256) {
+            // up to 4 edges per lane: the row's scores (8 heads at a time) stay in registers -- columns and values
+            // requested together, then the score rows, then maximum, sum and weights without another read
+            const int kmax = (dg + 63) / 64;
+            unsigned c[4];
+            unsigned pv = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k >= kmax) break;
+                const bool ok = lane + 64 * k < dg;
+                const unsigned off = ok ? (unsigned)(ge0 + lane + 64 * k) * 4u : kOOB;
+                c[k] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
+                float v;
+                if constexpr (sizeof(T) == 2) v = (float)__builtin_bit_cast(T, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0));
+                else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
+                pv |= (ok && v > 0.0f) ? (1u << k) : 0u;
+            }
+            for (int hb0 = 0; hb0 < n_heads; hb0 += 8) {
+                float si[8], m[8], l[8], x[4][8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { si[q] = hb0 + q < n_heads ? s1[gr * n_heads + hb0 + q] : 0.0f; m[q] = -INFINITY; l[q] = 0.0f; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= kmax) break;
+                    const bool ok = lane + 64 * k < dg;
+                    load_scores8(s2, ok ? (int64_t)c[k] : 0, n_heads, hb0, vec8, x[k]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[k][q] = leaky(si[q] + x[k][q], alpha);
+                    if (E && ok) store8(E, ge0 + lane + 64 * k, n_heads, hb0, vec8, x[k]);
+                    if ((pv >> k) & 1u) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], x[k][q]);
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], __shfl_xor(m[q], off));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= kmax) break;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        x[k][q] = (pv >> k) & 1u ? expf(x[k][q] - m[q]) : 0.0f;
+                        l[q] += x[k][q];
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) l[q] += __shfl_xor(l[q], off);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= kmax) break;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[k][q] = l[q] > 0.0f ? x[k][q] / l[q] : 0.0f;
+                    if (lane + 64 * k < dg) store8(W, ge0 + lane + 64 * k, n_heads, hb0, vec8, x[k]);
+                }
+                if (hb0 == 0 && lane == 0) dead[gr] = l[0] > 0.0f ? 0 : 1;
+            }
+            continue;
+        }
+        for (int hb0 = 0; hb0 < n_heads; hb0 += 8) {
+            float si[8], m[8], l[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { si[k] = hb0 + k < n_heads ? s1[gr * n_heads + hb0 + k] : 0.0f; m[k] = -INFINITY; l[k] = 0.0f; }
+            for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+                const int c = col[idx];
+                const bool pv = Elem<T>::to_f32(val[idx]) > 0.0f;
+                float sc[8];
+                load_scores8(s2, c, n_heads, hb0, vec8, sc);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[k] = leaky(si[k] + sc[k], alpha);
+                if (E) store8(E, idx, n_heads, hb0, vec8, sc);
+                if (pv) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], sc[k]);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], __shfl_xor(m[k], off));
+            }
+            for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+                const int c = col[idx];
+                if (Elem<T>::to_f32(val[idx]) > 0.0f) {
+                    float sc[8];
+                    load_scores8(s2, c, n_heads, hb0, vec8, sc);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) l[k] += expf(leaky(si[k] + sc[k], alpha) - m[k]);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) l[k] += __shfl_xor(l[k], off);
+            }
+            for (int idx = ge0 + lane; idx < ge1; idx += 64) {
+                const int c = col[idx];
+                const bool pv = Elem<T>::to_f32(val[idx]) > 0.0f;
+                float sc[8];
+                load_scores8(s2, c, n_heads, hb0, vec8, sc);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[k] = (pv && l[k] > 0.0f) ? expf(leaky(si[k] + sc[k], alpha) - m[k]) / l[k] : 0.0f;
+                store8(W, idx, n_heads, hb0, vec8, sc);
+            }
+            if (hb0 == 0 && lane == 0) dead[gr] = l[0] > 0.0f ? 0 : 1;
+        }
+    }
+}
+
+// Scores Wh.a1, Wh.a2 per (node, head) with the rows read 16 bytes per lane: a lane keeps the attention fragments of
+// its columns in registers and walks rows grid-stride; the lanes of a head (F_head / VEC of them, a power of two) fold
+// their partial dot products with shuffles.  One tile of LPR x VEC columns covers the row.
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gat_scores_rows_kernel(int n_rows, int n_feat, int n_heads, int f_head,
+                                                                const T *__restrict__ Wh, int64_t ldh,
+                                                                const T *__restrict__ att, float *__restrict__ s1,
+                                                                float *__restrict__ s2)
+{
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR, grp = lane / LPR;
+    const int col0 = sub * VEC;
+    const bool mine = col0 < n_feat;
+    const int h = mine ? col0 / f_head : 0, j0 = mine ? col0 - h * f_head : 0;
+    const int lanes_per_head = f_head / VEC;
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        a1[i] = mine ? Elem<T>::to_f32(att[(int64_t)h * 2 * f_head + j0 + i]) : 0.0f;
+        a2[i] = mine ? Elem<T>::to_f32(att[(int64_t)h * 2 * f_head + f_head + j0 + i]) : 0.0f;
+    }
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t r0 = wave * RPW; r0 < n_rows; r0 += n_waves * RPW) {
+        const int64_t r = r0 + grp;
+        float p1 = 0.0f, p2 = 0.0f;
+        if (r < n_rows && mine) {
+            union { u32x4 v; T e[VEC]; } u;
+            u.v = *reinterpret_cast<const u32x4 *>(Wh + r * ldh + col0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float x = Elem<T>::to_f32(u.e[i]);
+                p1 = __builtin_fmaf(x, a1[i], p1);
+                p2 = __builtin_fmaf(x, a2[i], p2);
+            }
+        }
+        for (int off = 1; off < lanes_per_head; off <<= 1) {
+            p1 += __shfl_xor(p1, off);
+            p2 += __shfl_xor(p2, off);
+        }
+        if (r < n_rows && mine && (sub % lanes_per_head) == 0) {
+            s1[r * n_heads + h] = p1;
+            s2[r * n_heads + h] = p2;
+        }
+    }
+}
+
+// long rows, step 1: one wavefront per task, its (max, sum) per head; E of its edges
+template <typename T, int HB>
+__global__ __launch_bounds__(kBlock) void gat_alpha_task_stats_kernel(
+    int n_tasks, int n_heads, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
+    const int32_t *__restrict__ task_e1, const int32_t *__restrict__ col, const T *__restrict__ val,
+    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, float *__restrict__ E,
+    float *__restrict__ pm, float *__restrict__ pl)
+{
+    const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = task_row[task];
+    const int te0 = task_e0[task], te1 = task_e1[task];
+    const bool vec8 = HB == 8 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(E)) % 16 == 0;
+    for (int hb0 = 0; hb0 < n_heads; hb0 += HB) {
+        float si[HB], m[HB], l[HB];
+#pragma unroll
+        for (int h = 0; h < HB; ++h) { si[h] = s1[r * n_heads + hb0 + h]; m[h] = -INFINITY; l[h] = 0.0f; }
+        for (int idx = te0 + lane; idx < te1; idx += 64) {
+            const int c = col[idx];
+            const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+            if constexpr (HB == 8) {
+                float sc[8];
+                load_scores8(s2, c, n_heads, hb0, vec8, sc);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) sc[h] = leaky(si[h] + sc[h], alpha);
+                if (E) store8(E, idx, n_heads, hb0, vec8, sc);
+                if (pos) {
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) online_add(m[h], l[h], sc[h]);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < HB; ++h) {
+                    const float x = leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha);
+                    if (E) E[(int64_t)idx * n_heads + hb0 + h] = x;
+                    if (pos) online_add(m[h], l[h], x);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int h = 0; h < HB; ++h) softmax_merge(m[h], l[h], __shfl_xor(m[h], off), __shfl_xor(l[h], off));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < HB; ++h) { pm[(int64_t)task * n_heads + hb0 + h] = m[h]; pl[(int64_t)task * n_heads + hb0 + h] = l[h]; }
+        }
+    }
+}
+
+// long rows, step 2: the tasks of a row merged in task order
+__global__ __launch_bounds__(kBlock) void gat_alpha_long_merge_kernel(
+    int n_long, int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
+    const float *__restrict__ pm, const float *__restrict__ pl, float *__restrict__ row_m, float *__restrict__ row_l,
+    unsigned char *__restrict__ dead)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)n_long * n_heads) return;
+    const int i = (int)(gid / n_heads), h = (int)(gid % n_heads);
+    float m = -INFINITY, l = 0.0f;
+    for (int t = long_first[i]; t < long_first[i + 1]; ++t) softmax_merge(m, l, pm[(int64_t)t * n_heads + h], pl[(int64_t)t * n_heads + h]);
+    row_m[gid] = m;
+    row_l[gid] = l;
+    if (h == 0) dead[long_row[i]] = l > 0.0f ? 0 : 1;
+}
+
+// long rows, step 3: the weights of their edges (workgroup (i, y) walks every gridDim.y-th 256-edge piece of long row i)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
+    int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const T *__restrict__ val, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
+    const float *__restrict__ row_m, const float *__restrict__ row_l, float *__restrict__ W)
+{
+    const int i = blockIdx.x;
+    const int64_t row = long_row[i];
+    const int e1 = rowptr[row + 1];
+    const bool vec8 = n_heads % 8 == 0 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(W)) % 16 == 0;
+    for (int idx = rowptr[row] + blockIdx.y * kBlock + threadIdx.x; idx < e1; idx += gridDim.y * kBlock) {
+        const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
+        const int c = col[idx];
+        for (int hb0 = 0; hb0 < n_heads; hb0 += 8) {
+            float sc[8];
+            load_scores8(s2, c, n_heads, hb0, vec8, sc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float w = 0.0f;
+                if (hb0 + k < n_heads) {
+                    const float m = row_m[(int64_t)i * n_heads + hb0 + k], l = row_l[(int64_t)i * n_heads + hb0 + k];
+                    if (pos && l > 0.0f) w = expf(leaky(s1[row * n_heads + hb0 + k] + sc[k], alpha) - m) / l;
+                }
+                sc[k] = w;
+            }
+            store8(W, idx, n_heads, hb0, vec8, sc);
+        }
+    }
+}
+
+// Stage B: D[r][:] = act(sum_e W[e][head of the column] * Wh[col[e]][:]).  Workgroups [0, split_blocks) sum the plan's
+// tasks (all lane groups of a wavefront on one task, fp32 partial rows), the others one row per lane group.  HEADS = 0:
+// one weight per edge, loaded with the column by the edge's lane and shuffled; HEADS = 1: every lane loads the weight
+// of its own head for each edge through a buffer resource (out of range past the row's end: 0, no access).
+template <typename T, int VEC, int LPR, int HEADS>
+__global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
+    int n_work, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const float *__restrict__ W, unsigned w_bytes, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
+    T *__restrict__ D, int64_t ldd, int relu, float out_scale, int long_threshold, int vec_store,
+    const int32_t *__restrict__ row_order, int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0,
+    const int32_t *__restrict__ task_e1, float *__restrict__ partial, int ldp)
+{
+    constexpr int RPW = 64 / LPR;
+    constexpr int TILE = LPR * VEC;
+    constexpr int UNR = LPR < 8 ? LPR : 8;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wh), 0, h_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, w_bytes, 0x00020000);
+
+    // the sums of edges [e0, e1) taken `stride` apart in pieces of LPR, for the lane's VEC columns at col0
+    auto accumulate = [&](float *acc, int e0, int e1, int stride, int col0) {
+        const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+        const unsigned my_head = HEADS ? (unsigned)((col0 < n_feat ? col0 : 0) / f_head) : 0u;
+        unsigned c_next = 0;
+        float a_next = 0.0f;
+        auto fetch = [&](int idx, unsigned &c, float &a) {
+            c = 0u;
+            a = 0.0f;
+            if (idx < e1) {
+                c = (unsigned)__builtin_nontemporal_load(col + idx);
+                if (!HEADS) a = __builtin_nontemporal_load(W + idx);
+            }
+        };
+        fetch(e0 + sub, c_next, a_next);
+        for (int base = e0; base < e1; base += stride) {
+            const unsigned c = c_next;
+            const float a = a_next;
+            fetch(base + stride + sub, c_next, a_next);
+            const int n = e1 - base;
+#pragma unroll 1
+            for (int t0 = 0; t0 < LPR; t0 += UNR) {
+                if (t0 >= n) break;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int t = t0 + u;
+                    const unsigned cc = (unsigned)__shfl((int)c, t, LPR);
+                    float aa;
+                    if (HEADS)
+                        aa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                 wsrc, t < n ? ((unsigned)(base + t) * (unsigned)n_heads + my_head) * 4u : kOOB, 0, 0));
+                    else
+                        aa = __shfl(a, t, LPR);
+                    Gather<T, VEC>::run(acc, aa, rsrc, (t < n && col_off != kOOB) ? cc * ld_bytes + col_off : kOOB);
+                }
+            }
+        }
+    };
+
+    if ((int)blockIdx.x < split_blocks) {
+        const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        if (task >= n_tasks) return;
+        const int e0 = task_e0[task], e1 = task_e1[task];
+        for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+            const int col0 = c0 + sub * VEC;
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+            accumulate(acc, e0 + grp * LPR, e1, 64, col0);
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off);
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    if (col0 + i < n_feat) partial[(int64_t)task * ldp + col0 + i] = acc[i];
+            }
+        }
+        return;
+    }
+    const int64_t wave = (int64_t)(blockIdx.x - split_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)(gridDim.x - split_blocks) * (kBlock / 64);
+    for (int64_t r0 = wave * RPW; r0 < n_work; r0 += n_waves * RPW) {
+        int64_t r = r0 + grp;
+        int e0 = 0, e1 = 0;
+        bool live = r < n_work;
+        if (live) {
+            if (row_order) r = row_order[r];
+            e0 = rowptr[r];
+            e1 = rowptr[r + 1];
+            if (long_threshold > 0 && e1 - e0 > long_threshold) live = false;
+        }
+        if (!live) e1 = e0;
+        for (int c0 = 0; c0 < n_feat; c0 += TILE) {
+            const int col0 = c0 + sub * VEC;
+            float acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+            accumulate(acc, e0, e1, LPR, col0);
+            if (live && col0 < n_feat) {
+                T out[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) out[i] = gat_finish<T>(acc[i], relu, out_scale);
+                T *drow = D + r * ldd;
+                if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
+                    *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        if (col0 + i < n_feat) drow[col0 + i] = out[i];
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_weighted_finalize_kernel(
+    int n_long, int n_feat, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
+    const float *__restrict__ partial, int ldp, T *__restrict__ D, int64_t ldd, int relu, float out_scale)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)n_long * n_feat) return;
+    const int l = (int)(gid / n_feat), j = (int)(gid % n_feat);
+    float s = 0.0f;
+    for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
+    D[(int64_t)long_row[l] * ldd + j] = gat_finish<T>(s, relu, out_scale);
+}
+
+// rows without a live edge: the row `fill` (the mean of all rows of Wh, SG.py:638-641) and S = 1/N on their edges
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_dead_fill_kernel(
+    int n_rows, int n_feat, int n_heads, const unsigned char *__restrict__ dead, const int32_t *__restrict__ rowptr,
+    const float *__restrict__ fill, float uniform, T *__restrict__ D, int64_t ldd, int relu, float out_scale,
+    float *__restrict__ S)
+{
+    const int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (r >= n_rows || !dead[r]) return;
+    const int lane = threadIdx.x & 63;
+    for (int j = lane; j < n_feat; j += 64) D[r * ldd + j] = gat_finish<T>(fill[j], relu, out_scale);
+    if (S)
+        for (int64_t i = (int64_t)rowptr[r] * n_heads + lane; i < (int64_t)rowptr[r + 1] * n_heads; i += 64) S[i] = uniform;
+}
+
+template <typename T, int HB>
+int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W, unsigned char *dead, float *pm, float *pl,
+                    float *row_m, float *row_l)
+{
+    const sgx_plan *p = a.plan_any;
+    const int thr = p->n_long > 0 ? p->long_threshold : 0;
+    const int rows_per_block = (64 / kAlphaLanes) * (kBlock / 64);
+    if (a.n_heads == 1) {
+        hipLaunchKernelGGL((gat_alpha_rows_1head_kernel<T>), dim3((unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block)),
+                           dim3(kBlock), 0, a.stream, a.n_rows, a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,
+                           (unsigned)((size_t)a.n_cols * 4), a.alpha, thr, W, a.E, dead);
+    } else if (a.n_heads <= 64) {
+        int lh = sgx_next_pow2(a.n_heads);
+        const int rpb = (64 / lh) * (kBlock / 64);
+        const dim3 grid((unsigned)((a.n_rows + rpb - 1) / rpb));
+#define SGX_GAT_LH(L)                                                                                                     \
+    case L:                                                                                                               \
+        hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads, a.rowptr, \
+                           a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                          \
+                           (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                        \
+        break;
+        switch (lh) {
+            SGX_GAT_LH(2) SGX_GAT_LH(4) SGX_GAT_LH(8) SGX_GAT_LH(16) SGX_GAT_LH(32) SGX_GAT_LH(64)
+        }
+#undef SGX_GAT_LH
+    } else {
+        hipLaunchKernelGGL((gat_alpha_rows_kernel<T, HB>), dim3((unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block)),
+                           dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, thr,
+                           W, a.E, dead);
+    }
+    SGX_LAUNCH_CHECK();
+    if (thr > 0) {
+        hipLaunchKernelGGL((gat_alpha_task_stats_kernel<T, HB>), dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
+                           0, a.stream, p->n_tasks, a.n_heads, p->task_row, p->task_e0, p->task_e1, a.col, (const T *)a.val, s1,
+                           s2, a.alpha, a.E, pm, pl);
+        SGX_LAUNCH_CHECK();
+        const int64_t pairs = (int64_t)p->n_long * a.n_heads;
+        hipLaunchKernelGGL(gat_alpha_long_merge_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream,
+                           p->n_long, a.n_heads, p->long_row, p->long_first, pm, pl, row_m, row_l, dead);
+        SGX_LAUNCH_CHECK();
+        hipLaunchKernelGGL((gat_alpha_long_write_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_heads,
+                           p->long_row, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, row_m, row_l, W);
+        SGX_LAUNCH_CHECK();
+    }
+    return SGX_OK;
+}
+
+template <typename T, int VEC, int LPR>
+int gat_two_stage(const GatArgs &a)
+{
+    const sgx_plan *p = a.plan_any;
+    const int rows_per_block = (64 / LPR) * (kBlock / 64);
+    const unsigned grid_s = (unsigned)((a.n_cols + rows_per_block - 1) / rows_per_block);
+    const int f_head = a.n_feat / a.n_heads;
+    float *s1 = a.s, *s2 = a.s + (size_t)a.n_cols * a.n_heads;
+    const int lanes_per_head = VEC > 1 ? f_head / VEC : 0;
+    if (VEC > 1 && a.vec_ok && a.n_feat <= LPR * VEC && f_head % VEC == 0 && lanes_per_head >= 1 && lanes_per_head <= LPR &&
+        (lanes_per_head & (lanes_per_head - 1)) == 0) {
+        int64_t blocks = ((int64_t)a.n_cols + rows_per_block - 1) / rows_per_block;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((gat_scores_rows_kernel<T, VEC, LPR>), dim3((unsigned)blocks), dim3(kBlock), 0, a.stream, a.n_cols,
+                           a.n_feat, a.n_heads, f_head, (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2);
+    } else if (a.n_heads > 1) {
+        const int64_t pairs = (int64_t)a.n_cols * a.n_heads;
+        hipLaunchKernelGGL((gat_scores_heads_kernel<T>), dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           a.stream, a.n_cols, a.n_heads, f_head, (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2);
+    } else {
+        hipLaunchKernelGGL((gat_scores_kernel<T, VEC, LPR>), dim3(grid_s), dim3(kBlock), 0, a.stream, a.n_cols, a.n_feat,
+                           (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2, a.vec_ok);
+    }
+    SGX_LAUNCH_CHECK();
+    // scratch behind the split area: the weights (unless the caller's S takes them) and the dead-row flags
+    const int thr = p->n_long > 0 ? p->long_threshold : 0;
+    const int ldp = (int)sgx_align_up((size_t)a.n_feat, 4);
+    float *pacc = a.split, *pm = pacc + (size_t)p->n_tasks * ldp, *pl = pm + (size_t)p->n_tasks * a.n_heads;
+    float *row_m = pl + (size_t)p->n_tasks * a.n_heads, *row_l = row_m + (size_t)p->n_long * a.n_heads;
+    float *W = a.S ? a.S : a.two_stage;
+    unsigned char *dead = reinterpret_cast<unsigned char *>(a.two_stage + (size_t)p->nnz * a.n_heads);
+    int rc;
+    if (a.n_heads % 8 == 0) rc = gat_alpha_stage<T, 8>(a, s1, s2, W, dead, pm, pl, row_m, row_l);
+    else if (a.n_heads % 4 == 0) rc = gat_alpha_stage<T, 4>(a, s1, s2, W, dead, pm, pl, row_m, row_l);
+    else if (a.n_heads % 2 == 0) rc = gat_alpha_stage<T, 2>(a, s1, s2, W, dead, pm, pl, row_m, row_l);
+    else rc = gat_alpha_stage<T, 1>(a, s1, s2, W, dead, pm, pl, row_m, row_l);
+    if (rc != SGX_OK) return rc;
+
+    const int32_t *order = p->row_order;
+    const int n_work = order ? p->n_ordered : a.n_rows;
+    const int n_tasks = thr > 0 ? p->n_tasks : 0;
+    const int split_blocks = (n_tasks + kBlock / 64 - 1) / (kBlock / 64);
+    int64_t row_blocks = ((int64_t)n_work + rows_per_block - 1) / rows_per_block;
+    if (row_blocks > 256 * 512) row_blocks = 256 * 512;
+    const unsigned w_bytes = (unsigned)((size_t)p->nnz * a.n_heads * sizeof(float));
+    if (a.n_heads > 1)
+        hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, 1>), dim3((unsigned)(split_blocks + row_blocks)), dim3(kBlock), 0,
+                           a.stream, n_work, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes,
+                           a.ld_bytes, (T *)a.D, a.ldd, a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks,
+                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, pacc, ldp);
+    else
+        hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, 0>), dim3((unsigned)(split_blocks + row_blocks)), dim3(kBlock), 0,
+                           a.stream, n_work, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes,
+                           a.ld_bytes, (T *)a.D, a.ldd, a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks,
+                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, pacc, ldp);
+    SGX_LAUNCH_CHECK();
+    if (n_tasks > 0) {
+        const int64_t total = (int64_t)p->n_long * a.n_feat;
+        hipLaunchKernelGGL((gat_weighted_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           a.stream, p->n_long, a.n_feat, p->long_row, p->long_first, pacc, ldp, (T *)a.D, a.ldd, a.relu,
+                           a.out_scale);
+        SGX_LAUNCH_CHECK();
+    }
+    if (a.fill) {
+        hipLaunchKernelGGL((gat_dead_fill_kernel<T>), dim3((unsigned)((a.n_rows + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                           a.stream, a.n_rows, a.n_feat, a.n_heads, dead, a.rowptr, a.fill, 1.0f / (float)a.uniform_n, (T *)a.D,
+                           a.ldd, a.relu, a.out_scale, a.S);
+        SGX_LAUNCH_CHECK();
+    }
+    return SGX_OK;
+}
+
 template <typename T, int VEC>
 int gat_launch_lpr(const GatArgs &a, int lpr)
 {
@@ -633,6 +1550,23 @@ size_t base_scratch_floats(int n_cols, int n_feat, int n_heads, int fill_dead_ro
     return sgx_align_up(floats, 64);
 }
 bool uses_split(const sgx_plan *plan) { return plan && plan->n_long > 0; }
+size_t split_floats(const sgx_plan *plan, int n_feat, int n_heads)
+{
+    if (!uses_split(plan)) return 0;     // per task: fp32 partial row + (max, sum) per head; per long row: (max, sum) per head
+    return sgx_align_up((size_t)plan->n_tasks * (sgx_align_up((size_t)n_feat, 4) + 2 * (size_t)n_heads) +
+                        (size_t)2 * plan->n_long * n_heads, 64);
+}
+// the two-stage form needs the stored-entry count on the host (a plan carries it) and 32-bit offsets into the weights
+bool two_stage_ok(const sgx_plan *plan, int n_heads)
+{
+    if (getenv("SGX_GAT_ONE_PASS")) return false;           // tuning override: the one-pass kernels
+    return plan && plan->nnz > 0 && (unsigned long long)plan->nnz * (unsigned long long)n_heads < (1ull << 30) &&
+           (unsigned long long)plan->n_rows * (unsigned long long)n_heads < (1ull << 30);
+}
+size_t two_stage_floats(const sgx_plan *plan, int n_heads)
+{
+    return two_stage_ok(plan, n_heads) ? (size_t)plan->nnz * n_heads + ((size_t)plan->n_rows + 3) / 4 + 16 : 0;
+}
 }  // namespace
 
 extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan)
@@ -640,9 +1574,7 @@ extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int
     if (n_cols < 0 || n_feat < 1) return 0;
     if (n_heads < 1) n_heads = 1;
     size_t floats = base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
-    if (uses_split(plan))        // per task: fp32 partial row + (max, sum) per head; per long row: (max, sum) per head
-        floats += (size_t)plan->n_tasks * (sgx_align_up((size_t)n_feat, 4) + 2 * (size_t)n_heads) +
-                  (size_t)2 * plan->n_long * n_heads;
+    floats += split_floats(plan, n_feat, n_heads) + two_stage_floats(plan, n_heads);
     return sgx_align_up(floats * sizeof(float), 256);
 }
 
@@ -721,6 +1653,8 @@ int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, in
     a.uniform_n = ext_fill ? ext_n : n_cols;
     a.plan = uses_split(plan) ? plan : nullptr;
     a.split = s_scratch + base_scratch_floats(n_cols, n_feat, n_heads, fill_dead_rows);
+    a.plan_any = plan;
+    a.two_stage = two_stage_ok(plan, n_heads) ? a.split + split_floats(plan, n_feat, n_heads) : nullptr;
     if (fill_dead_rows) {
         float *partial = s_scratch + (size_t)2 * n_cols * n_heads, *mean = partial + (size_t)kMeanSlabs * n_feat;
         if (dtype == SGX_F16)

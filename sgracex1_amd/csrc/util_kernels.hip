@@ -276,8 +276,18 @@ extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_
 // 6144: 2.04, 8192: 2.32 -- a lane group walks a 4096-edge row in 512 steps while the degree-ordered schedule
 // keeps its wavefront full, and every task costs a partial row and a finalize read.  (The GAT aggregate, with
 // its softmax state per step, prefers 512: sgx_plan_create_ex.)
+// The best cut moves with the size of the graph -- a launch of a smaller graph is over before a 4096-edge row's 512
+// dependent steps are (tools/plan_cut_probe.py, R-MAT, cut / ms of the plain aggregate: 2.4 M edges 512 / 0.136 against
+// 4096 / 0.400; 7.5 M edges 1024 / 0.179 against 0.241; 29 M edges 2048 / 0.448 against 0.786; 104 M edges 4096): the
+// optimum follows sqrt(nnz) / 2 rounded down to a power of two, which is what default_cut returns.
 static const int kLongThreshold = 4096;
 static const int kChunk = 4096;
+static int default_cut(int64_t nnz)
+{
+    int cut = 64;
+    while (cut < kLongThreshold && (int64_t)(2 * cut) * (2 * cut) * 4 <= nnz) cut *= 2;      // 2 cut <= sqrt(nnz) / 2
+    return cut;
+}
 // Small matrices finish in microseconds and their time IS the longest row's chain of dependent
 // steps (Cora: 168 edges = 21 steps on one lane group), so there rows are cut much earlier: a
 // 64-edge task is one step for every lane group of its wavefront.
@@ -303,8 +313,8 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     SGX_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<int32_t> long_row, long_first, task_row, task_e0, task_e1;
     const bool small = rp[(size_t)n_rows] < kSmallNnz;
-    int long_threshold = small ? kSmallThreshold : kLongThreshold;
-    int chunk = small ? kSmallChunk : kChunk;
+    int long_threshold = small ? kSmallThreshold : default_cut(rp[(size_t)n_rows]);
+    int chunk = small ? kSmallChunk : long_threshold;
     if (!small && long_threshold_arg >= 8) {                          // the caller's cut (large matrices only)
         long_threshold = long_threshold_arg / 8 * 8;
         chunk = chunk_arg >= 8 ? chunk_arg / 8 * 8 : long_threshold;

@@ -175,10 +175,13 @@ class Csr:
 
     @property
     def gat_plan(self):
-        """The schedule for the edge-softmax aggregate: hub rows are cut at 512 edges there (the default plan's
-        4096 suits the plain aggregation; measured in DESIGN.md 4)."""
+        """The schedule for the edge-softmax aggregate: hub rows cut at 256 edges.  Its first stage (the softmax weights,
+        csrc/gat.hip) keeps a row of up to 256 edges in registers; longer rows go through the plan's tasks.  Measured on
+        R-MAT graphs of 2.4 M / 7.5 M / 29 M edges (tools/plan_cut_probe.py): 256 is the best or within 2 % of it for one
+        head and for 8, while the plain aggregation prefers 512 / 1024 / 2048 (Plan's default).  The plan also tells the
+        library the stored-entry count it sizes the weights with."""
         if getattr(self, "_gat_plan", None) is None:
-            self._gat_plan = Plan(self.rowptr, 512, 512)
+            self._gat_plan = Plan(self.rowptr, 256, 256)
         return self._gat_plan
 
     @property

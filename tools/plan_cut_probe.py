@@ -38,7 +38,7 @@ for name, n, e, P in shapes:
     att = ((torch.rand(2 * P, generator=g, device=dev) * 2 - 1) * 0.3).half()
     D = torch.empty((n, P), dtype=torch.float16, device=dev)
     rec = {"graph": name, "nodes": n, "edges": A.nnz, "width": P, "max_degree": int(A.rowptr.diff().max())}
-    for cut in (64, 128, 256, 512, 1024, 2048, 4096):
+    for cut in [int(c) for c in os.environ.get("CUTS", "64,128,256,512,1024,2048,4096").split(",")]:
         plan = ops.Plan(A.rowptr, cut, cut)
         A._plan = plan
         A._gat_plan = plan
