@@ -181,10 +181,11 @@ def test_gatconv_sgrace_acc_vs_dense_emulation(compute_attention):
 
 
 def test_mutag_training_reaches_reference_accuracy():
-    """molecule_gcn end to end (MOL cells 6-20): 188-graph batch, hidden 64, Adam lr 0.01, fp16
-    kernels in forward, torch backward; the notebook reports test accuracy 0.62 -> 0.76 at epoch
-    34 on graphs [50:100] of its shuffle.  The shuffle depends on the torch version, so the bar
-    here is: the training loss falls and the same 50-graph slice reaches >= 0.72 within 60 epochs."""
+    """molecule_gcn end to end (MOL cells 6-20): 188-graph batch, hidden 64, Adam lr 0.01, dropout 0.5, model seed
+    12345, fp16 kernels; the notebook reports test accuracy 0.62 -> 0.76 at epoch 34 on graphs [50:100] of its
+    shuffle (the permutation depends on the torch version, so 0.76 is approximate).  Both branches of the model's `acc`
+    switch are trained from the same seeds on the same split: acc = 1 (the kernels) must reach the accuracy of acc = 0
+    (the notebook's own torch path, the parity twin) to within one graph of the 50 (0.02), and at least 0.74."""
     from sgracex1_amd import molecule_gcn as M, pyg_lite as G, pynq_shim
     dev = torch.device("cuda")
     raw = np.load(os.path.join(GOLD, "mutag_raw.npz"))
@@ -194,23 +195,35 @@ def test_mutag_training_reaches_reference_accuracy():
     graphs = [graphs[i] for i in perm]
     train, test = G.collate(graphs[:2000]).to(dev), G.collate(graphs[50:100]).to(dev)
     ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
-    model = M.GCN_PYNQ(64, 7, 2, ip).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01)
-    crit = torch.nn.CrossEntropyLoss()
-    losses, best = [], 0.0
-    for epoch in range(60):
-        model.train()
-        opt.zero_grad()
-        loss = crit(model(1, train.x, train.edge_index, train.batch), train.y)
-        loss.backward()
-        opt.step()
-        losses.append(float(loss))
-        model.eval()
-        with torch.no_grad():
-            pred = model(1, test.x, test.edge_index, test.batch).argmax(dim=1)
-        best = max(best, float((pred == test.y).float().mean()))
-    assert losses[-1] < losses[0]
-    assert best >= 0.72, best
+
+    def run(acc, epochs=100):
+        torch.manual_seed(12345)                                   # MOL cell 18: the model's seed
+        model = M.GCN_PYNQ(64, 7, 2, ip).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+        crit = torch.nn.CrossEntropyLoss()
+        torch.manual_seed(777)                                     # the dropout masks of both runs
+        losses, accs = [], []
+        for _epoch in range(epochs):
+            model.train()
+            opt.zero_grad()
+            loss = crit(model(acc, train.x, train.edge_index, train.batch), train.y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            model.eval()
+            with torch.no_grad():
+                pred = model(acc, test.x, test.edge_index, test.batch).argmax(dim=1)
+            accs.append(float((pred == test.y).float().mean()))
+        first = next((i + 1 for i, a in enumerate(accs) if a >= 0.76 - 1e-6), None)
+        return max(accs), first, losses
+
+    best1, first1, losses1 = run(1)
+    best0, first0, losses0 = run(0)
+    print(f"molecule_gcn: acc=1 best {best1:.2f} (0.76 first reached at epoch {first1}), acc=0 best {best0:.2f} "
+          f"(epoch {first0}); reference notebook: 0.76 at epoch 34")
+    assert losses1[-1] < losses1[0] and losses0[-1] < losses0[0]
+    assert best1 >= 0.74, best1
+    assert best1 >= best0 - 0.02, (best1, best0)
 
 
 def test_two_layer_forward_replayed_from_a_hipgraph(oracle):
