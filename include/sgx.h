@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 103
+#define SGX_VERSION 104
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -100,6 +100,11 @@ int sgx_plan_reordered(const sgx_plan *plan);
  * multiplied by deq_o.  All of it in fp32 (dtype must be SGX_F32).  The fields are the registers of
  * the GAT bitstream (SG.py:335-365, :476; demo/zcu104/gat_all_unsigned.hwh). */
 #define SGX_QUANT_ADJ_DONE 1   /* flags: values_adj already hold quantised values (graph cached by the host) */
+#define SGX_QUANT_INT8 2       /* flags: gemm_mode 1, qbits <= 8, P_w <= 256: X and W go to the int8 matrix cores as the
+                                  integer codes of their grids (sgx_quantize_codes_i8 + sgx_xw_dense_i8) -- X.W summed
+                                  exactly in int32 instead of in fp32, X read as 1 byte per element.  Equal to the fp32
+                                  form whenever that form's sums are exact (|sum of code products| < 2^24), to fp32
+                                  rounding otherwise.  Ignored (fp32 form) where it does not apply.              */
 typedef struct sgx_quant {
     int32_t qbits;              /* config.w_qbits: 8, 4, 2 or 1                                       */
     int32_t scale_fea;          /* register scale_fea                                                 */
@@ -125,6 +130,21 @@ typedef struct sgx_quant {
 int sgx_fake_quantize(int is_signed, int qbits, float inv_scale, float zero, int64_t n, const float *x,
                       float *out, void *stream);
 int sgx_requantize(int n_rows, int n_feat, int64_t ld, float *H, int scale_fea, int internal_bits, void *stream);
+
+/* Integer operands (what the EIGHTBIT / quantised builds do in hardware, MM.h:85-118): the codes of the w_qbits grids
+ * as bytes.  codes[r][c] = clip(round(x / s + z)) - sgx_code_bias(is_signed, qbits), columns n_cols..ldc-1 = 0
+ * (unsigned 8-bit codes 0..255 are stored minus 128; every other grid fits a signed byte as it is); value = code /
+ * 2^(qbits-1) (1 bit: code / 2).  ldc a multiple of 16, codes 16-byte aligned for sgx_xw_dense_i8. */
+int sgx_code_bias(int is_signed, int qbits);
+int sgx_quantize_codes_i8(int is_signed, int qbits, float inv_scale, float zero, int n_rows, int n_cols, const float *x,
+                          int64_t ldx, int8_t *codes, int64_t ldc, void *stream);
+/* H[r][p] = requant( (sum_k Xc[r][k] Wc[p][k] + bias terms) / 2^(2(qbits-1)) ) on v_mfma_i32_16x16x64_i8: Xc unsigned
+ * feature codes [n_rows][ldx], Wc signed weight codes in the layout of B, [P][ldw]; the epilogue is the fp32 form's
+ * (shift by scale_fea, clip, decimal rounding; internal_bits = 0: none).  P <= 256.  workspace:
+ * sgx_xw_dense_i8_workspace_bytes(P) bytes. */
+size_t sgx_xw_dense_i8_workspace_bytes(int P);
+int sgx_xw_dense_i8(int qbits, int n_rows, int M_fea, int P, const int8_t *Xc, int64_t ldx, const int8_t *Wc, int64_t ldw,
+                    int scale_fea, int internal_bits, float *H, int64_t ldh, void *workspace, void *stream);
 
 /* ---- the layer: replaces mmult_top / kernelmult1 (K.cpp:3762, :3969; KH:13-58) ------ */
 typedef enum sgx_layer_order {

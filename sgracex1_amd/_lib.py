@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("SGX_LIB_PATH") or os.path.join(_HERE, "csrc", "libsgx
 SGX_F16, SGX_F32 = 0, 1
 SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 SGX_ORDER_REFERENCE, SGX_ORDER_AGGREGATE_FIRST = 0, 1      # sgx_layer_order
+SGX_QUANT_INT8 = 2                                          # sgx_quant.flags: integer operands on the int8 matrix cores
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
@@ -30,6 +31,7 @@ SYMBOLS = [
     "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear", "sgx_gat_backward_edges",
     "sgx_stream_copy", "sgx_xw_dense_act", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_gat_aggregate_fill", "sgx_col_sums", "sgx_col_sums_scratch_bytes", "sgx_pack_rows",
+    "sgx_code_bias", "sgx_quantize_codes_i8", "sgx_xw_dense_i8", "sgx_xw_dense_i8_workspace_bytes",
     "sgx_version", "sgx_status_string",
 ]
 
@@ -133,6 +135,14 @@ def _load():
     lib.sgx_col_sums_scratch_bytes.restype = sz
     lib.sgx_col_sums.argtypes = [c_int, c_int, c_int, vp, c_i64, vp, vp, vp]
     lib.sgx_col_sums.restype = c_int
+    lib.sgx_code_bias.argtypes = [c_int, c_int]
+    lib.sgx_code_bias.restype = c_int
+    lib.sgx_quantize_codes_i8.argtypes = [c_int, c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, vp, c_i64, vp, c_i64, vp]
+    lib.sgx_quantize_codes_i8.restype = c_int
+    lib.sgx_xw_dense_i8_workspace_bytes.argtypes = [c_int]
+    lib.sgx_xw_dense_i8_workspace_bytes.restype = sz
+    lib.sgx_xw_dense_i8.argtypes = [c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, c_int, c_int, vp, c_i64, vp, vp]
+    lib.sgx_xw_dense_i8.restype = c_int
     lib.sgx_pack_rows.argtypes = [c_int, c_i64, c_int, vp, c_i64, vp, vp, c_i64, vp]
     lib.sgx_pack_rows.restype = c_int
     lib.sgx_csr_validate.argtypes = [vp, vp, c_int, c_int, c_i64, vp]

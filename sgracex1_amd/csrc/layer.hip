@@ -16,6 +16,8 @@ struct Carve {
     size_t g_off, g_bytes;        // GAT per-node scores, 2*N floats
     size_t q_off, q_bytes;        // quantised layer: copies of B, X (values), A (values), attention
     size_t qb, qx, qa, qt;        //   their offsets inside the q block
+    size_t qw;                    //   int8 form: column sums of the weight codes
+    int64_t ldc;                  //   int8 form: row pitch of the code matrices (bytes, multiple of 16); 0 = fp32 form
     size_t total;
 };
 
@@ -28,9 +30,17 @@ bool repitch_x(const sgx_layer_desc *d)
     return sgx_ldh(d->dtype, d->M_fea) != d->M_fea && (int64_t)d->M_adj * d->M_fea >= (int64_t)1 << 22;
 }
 
+// the int8 operand form applies to a dense X with codes of at most 8 bits and an output of at most 256 columns
+bool int8_form(const sgx_layer_desc *d)
+{
+    return d->quant && (d->quant->flags & SGX_QUANT_INT8) && d->gemm_mode == 1 && d->quant->qbits <= 8 && d->P_w <= 256;
+}
+
 Carve carve(const sgx_layer_desc *d)
 {
     Carve c;
+    c.qw = 0;
+    c.ldc = 0;
     const size_t es = sgx_elem_size(d->dtype);
     const size_t ldh = (size_t)sgx_ldh(d->dtype, d->P_w);
     size_t off = 0;
@@ -56,8 +66,15 @@ Carve carve(const sgx_layer_desc *d)
     if (d->quant) {
         const sgx_quant *q = d->quant;
         size_t o = 0;
-        c.qb = o; o += sgx_align_up((size_t)d->P_w * d->M_fea * 4, 256);
-        c.qx = o; o += sgx_align_up((d->gemm_mode == 0 ? (size_t)q->nnz_fea : (size_t)d->M_adj * d->M_fea) * 4, 256);
+        if (int8_form(d)) {
+            c.ldc = (int64_t)sgx_align_up((size_t)d->M_fea, 16);
+            c.qb = o; o += sgx_align_up((size_t)d->P_w * c.ldc, 256);
+            c.qx = o; o += sgx_align_up((size_t)d->M_adj * c.ldc, 256);
+            c.qw = o; o += sgx_xw_dense_i8_workspace_bytes(d->P_w);
+        } else {
+            c.qb = o; o += sgx_align_up((size_t)d->P_w * d->M_fea * 4, 256);
+            c.qx = o; o += sgx_align_up((d->gemm_mode == 0 ? (size_t)q->nnz_fea : (size_t)d->M_adj * d->M_fea) * 4, 256);
+        }
         c.qa = o; o += (q->flags & SGX_QUANT_ADJ_DONE) ? 0 : sgx_align_up((size_t)q->nnz_adj * 4, 256);
         c.qt = o; o += d->gat_mode ? sgx_align_up((size_t)2 * d->P_w * 4, 256) : 0;
         c.q_bytes = o; off += o;
@@ -165,11 +182,21 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         if (!d->values_adj) return SGX_ERR_NULL;
         float *qbase = (float *)(ws + c.q_off);
         float *Bq = (float *)((char *)qbase + c.qb), *Xq = (float *)((char *)qbase + c.qx);
-        rc = sgx_fake_quantize(1, q->qbits, q->inv_scale_w, q->zero_w, (int64_t)d->P_w * d->M_fea, (const float *)d->B, Bq, s);
-        if (rc != SGX_OK) return rc;
-        const int64_t nx = d->gemm_mode == 0 ? q->nnz_fea : (int64_t)d->M_adj * d->M_fea;
-        rc = sgx_fake_quantize(0, q->qbits, q->inv_scale_fea, q->zero_fea, nx, (const float *)d->values_fea, Xq, s);
-        if (rc != SGX_OK) return rc;
+        if (c.ldc) {
+            // integer codes for the int8 matrix cores: weights signed, features unsigned (8-bit codes stored minus 128)
+            rc = sgx_quantize_codes_i8(1, q->qbits, q->inv_scale_w, q->zero_w, d->P_w, d->M_fea, (const float *)d->B, d->M_fea,
+                                       (int8_t *)Bq, c.ldc, s);
+            if (rc != SGX_OK) return rc;
+            rc = sgx_quantize_codes_i8(0, q->qbits, q->inv_scale_fea, q->zero_fea, d->M_adj, d->M_fea, (const float *)d->values_fea,
+                                       d->M_fea, (int8_t *)Xq, c.ldc, s);
+            if (rc != SGX_OK) return rc;
+        } else {
+            rc = sgx_fake_quantize(1, q->qbits, q->inv_scale_w, q->zero_w, (int64_t)d->P_w * d->M_fea, (const float *)d->B, Bq, s);
+            if (rc != SGX_OK) return rc;
+            const int64_t nx = d->gemm_mode == 0 ? q->nnz_fea : (int64_t)d->M_adj * d->M_fea;
+            rc = sgx_fake_quantize(0, q->qbits, q->inv_scale_fea, q->zero_fea, nx, (const float *)d->values_fea, Xq, s);
+            if (rc != SGX_OK) return rc;
+        }
         B = Bq; values_fea = Xq;
         if (!(q->flags & SGX_QUANT_ADJ_DONE)) {
             float *Aq = (float *)((char *)qbase + c.qa);
@@ -194,7 +221,10 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     }
 
     // stage 1: H = X . W          (loop_fea, K.cpp:2932)
-    if (d->gemm_mode == 0) {
+    if (c.ldc) {
+        rc = sgx_xw_dense_i8(q->qbits, d->M_adj, d->M_fea, d->P_w, (const int8_t *)values_fea, c.ldc, (const int8_t *)B, c.ldc,
+                             q->scale_fea, q->internal_bits, (float *)H, ldh, ws + c.q_off + c.qw, s);
+    } else if (d->gemm_mode == 0) {
         rc = sgx_transpose(d->dtype, d->P_w, d->M_fea, B, d->M_fea, W, ldh, s);         // B [P][M] -> W [M][ldh]
         if (rc != SGX_OK) return rc;
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, /*relu*/0, d->M_adj, d->M_fea, d->P_w, d->rowPtr_fea,

@@ -368,7 +368,7 @@ def transpose(x, ldo=None):
     return out
 
 
-def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False,
+def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_edge_outputs=False, quant_int8=False,
                   acc_mode=SGX_ACC_F32, spmm_block=1, bias_count=0, out=None, use_plan=True, agg_events=None,
                   quant=None, adj_quantized=False, cache_quantized_adj=True, fea_threads=1, adj_threads=1,
                   gat_heads=1, order="reference"):
@@ -378,7 +378,8 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     Wt  : [P, M_fea] -- the weights TRANSPOSED, what the reference writes into B_buffer.
     Returns D [N, P] (and (E, S) per-edge tensors when want_edge_outputs with GAT).
     quant: a quant.QuantConstants -- run the layer with the quantised arithmetic of the SGRACE
-    bitstream (fp32 tensors only); adj_quantized: adj.val already went through the quantiser;
+    bitstream (fp32 tensors only); quant_int8: with dense features, X and W go to the int8 matrix cores as the integer
+    codes of their grids (SGX_QUANT_INT8: exact int32 sums, X read as bytes); adj_quantized: adj.val already went through the quantiser;
     cache_quantized_adj: quantise the adjacency once per graph on the host side instead of inside
     every call (always done for GAT, whose mask decides how rows without a live edge are treated).
     order: "reference" -- X.W first, as the reference's dataflow; "aggregate_first" -- D = act((A.X).W), which
@@ -448,6 +449,8 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
         d.ev_agg_begin, d.ev_agg_end = agg_events
     if quant is not None:
         qs = quant.as_struct(nnz_adj=adj.nnz, nnz_fea=fea.nnz if gemm_mode == 0 else 0, adj_done=adj_quantized)
+        if quant_int8:
+            qs.flags |= _lib.SGX_QUANT_INT8
         d.quant = ctypes.pointer(qs)
     nbytes = lib.sgx_layer_workspace_bytes(ctypes.byref(d))
     ws = _workspace(Wt.device, nbytes)
@@ -466,6 +469,31 @@ def fake_quantize(x, signed, qbits, scale, zero, out=None):
     check(lib.sgx_fake_quantize(int(bool(signed)), int(qbits), float(1 / scale), float(zero), x.numel(), _ptr(x), _ptr(out),
                                 _stream()), "sgx_fake_quantize")
     return out
+
+
+def quantize_codes_i8(x, signed, qbits, scale, zero):
+    """The integer codes of an fp32 matrix on its w_qbits grid as int8 [rows, pitch] (pitch = columns rounded up to
+    16, pad codes 0); unsigned 8-bit codes are stored minus 128 (sgx_quantize_codes_i8).  Returns (codes, bias)."""
+    _dev2d(x, "x")
+    if x.dtype != torch.float32:
+        raise TypeError("codes are taken from float32 values (SG.py:1545)")
+    n, m = x.shape
+    ldc = (m + 15) // 16 * 16
+    codes = torch.empty((n, ldc), dtype=torch.int8, device=x.device)
+    check(lib.sgx_quantize_codes_i8(int(bool(signed)), int(qbits), float(1 / scale), float(zero), n, m, _ptr(x), x.stride(0),
+                                    _ptr(codes), ldc, _stream()), "sgx_quantize_codes_i8")
+    return codes, lib.sgx_code_bias(int(bool(signed)), int(qbits))
+
+
+def xw_dense_i8(Xc, Wc, M_fea, qbits, scale_fea=0, internal_bits=0):
+    """H = requant((Xc . Wc^T + bias terms) / 2^(2(qbits-1))) on the int8 matrix cores (sgx_xw_dense_i8): Xc unsigned
+    feature codes [n, pitch], Wc signed weight codes [P, pitch] as quantize_codes_i8 returns them."""
+    n, P = Xc.shape[0], Wc.shape[0]
+    H = torch.empty((n, P), dtype=torch.float32, device=Xc.device)
+    ws = torch.empty(max(1, lib.sgx_xw_dense_i8_workspace_bytes(P)), dtype=torch.uint8, device=Xc.device)
+    check(lib.sgx_xw_dense_i8(int(qbits), n, int(M_fea), P, _ptr(Xc), Xc.stride(0), _ptr(Wc), Wc.stride(0), int(scale_fea),
+                              int(internal_bits), _ptr(H), H.stride(0), _ptr(ws), _stream()), "sgx_xw_dense_i8")
+    return H
 
 
 def requantize_(H, scale_fea, internal_bits):

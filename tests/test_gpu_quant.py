@@ -207,3 +207,70 @@ def test_register_path_carries_the_quantiser_registers():
     assert rm.CTRL.AP_DONE == 1
     got = torch.from_numpy(np.asarray(bufs["D"]).reshape(n, p).copy())
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-6 * c.deq_o)
+
+
+# ---- integer operands on the int8 matrix cores (csrc/quant_i8.hip, SGX_QUANT_INT8) -------------------------------
+@pytest.mark.parametrize("bits", [8, 4, 2, 1])
+@pytest.mark.parametrize("signed", [0, 1])
+def test_integer_codes_are_the_grid_points(bits, signed):
+    """sgx_quantize_codes_i8: code / 2^(bits-1) (1 bit: code / 2) is exactly what the fp32 quantiser returns, at every
+    tie point of the grid and outside its range; unsigned 8-bit codes are stored minus 128; pad columns are 0."""
+    from sgracex1_amd import ops, quant
+    c = quant.constants(bits)
+    s, z = (c.w_s, c.w_z) if signed else (c.f_s, c.f_z)
+    x = _points(s, 50_000 - 50_606 % 37, bits * 2 + signed)
+    x = x[: x.numel() // 37 * 37].reshape(-1, 37).contiguous().to(dev)
+    codes, bias = ops.quantize_codes_i8(x, signed, bits, s, z)
+    assert bias == (128 if (bits == 8 and not signed) else 0) and codes.shape[1] == 48 and not codes[:, 37:].any()
+    frac = 1 if bits == 1 else bits - 1
+    value = (codes[:, :37].to(torch.int32) + bias).float() / 2 ** frac
+    assert torch.equal(value, ops.fake_quantize(x, signed, bits, s, z))
+
+
+@pytest.mark.parametrize("bits,n,M,P", [(8, 5000, 100, 47), (8, 3001, 128, 256), (8, 777, 602, 128), (8, 40, 7, 3),
+                                        (4, 5000, 300, 64), (2, 1000, 130, 24), (1, 1000, 65, 16)])
+def test_int8_matrix_cores_sum_exactly(bits, n, M, P):
+    """sgx_xw_dense_i8 without its epilogue against the integer product of the codes formed in int64: the same number
+    in every element (MFMA operand layout, the -128 repair of unsigned 8-bit codes, ragged K and P, rows past the last
+    tile)."""
+    from sgracex1_amd import ops, quant
+    c = quant.constants(bits)
+    g = torch.Generator(device=dev)
+    g.manual_seed(bits * 1000 + M)
+    x = torch.rand((n, M), generator=g, device=dev) * 1.2 - 0.1
+    w = (torch.rand((P, M), generator=g, device=dev) * 2 - 1) * 1.1 * (c.w_s * 2 ** (bits - 1))
+    Xc, xb = ops.quantize_codes_i8(x, 0, bits, c.f_s, c.f_z)
+    Wc, wb = ops.quantize_codes_i8(w, 1, bits, c.w_s, c.w_z)
+    assert wb == 0
+    H = ops.xw_dense_i8(Xc, Wc, M, bits)
+    exact = ((Xc[:, :M].double() + xb) @ Wc[:, :M].double().t())          # integers below 2^53: exact in double
+    frac = 1 if bits == 1 else bits - 1
+    assert exact.abs().max() < 2 ** 24 or bits == 8                  # (602 x 255 x 127 passes 2^24: rounded once, below)
+    want = (exact / 4.0 ** frac).float()
+    assert torch.equal(H, want)
+    assert H.abs().max() > 0
+
+
+@pytest.mark.parametrize("bits,gat,m", [(8, 0, 150), (8, 1, 150), (4, 0, 150), (4, 1, 300), (2, 0, 150), (1, 1, 150), (8, 0, 602)])
+def test_quantised_layer_with_integer_operands(bits, gat, m):
+    """The layer with SGX_QUANT_INT8 against its fp32 form: the same bits wherever the fp32 form's sums are exact
+    (products of codes sum below 2^24), fp32 rounding of H apart otherwise (M_fea 602 at 8 bits) -- and inside the
+    same band of the CPU restatement."""
+    from sgracex1_amd import ops, quant
+    n, p = 700, 24
+    adj, x, w, att = _graph_case(n, m, p, 77 + bits + gat)
+    c = quant.constants(bits)
+    A = ops.Csr.from_dense(adj.to(dev), torch.float32)
+    X, Wt = x.to(dev), w.t().contiguous().to(dev)
+    kw = dict(relu=True, gat_attention=att.reshape(-1).to(dev) if gat else None, quant=c)
+    ref = ops.layer_forward(A, X, Wt, **kw)
+    got = ops.layer_forward(A, X, Wt, quant_int8=True, **kw)
+    if m <= 500:
+        assert torch.equal(got, ref)
+    else:
+        assert torch.allclose(got, ref, rtol=2e-5, atol=2e-6 * c.deq_o)
+    want, _e, _p, _wh = QO.layer(adj, x, w, att, c, relu=1, compute_attention=gat)
+    assert torch.allclose(got.cpu(), want, rtol=2e-5, atol=2e-6 * c.deq_o)
+    # a sparse X keeps the fp32 form (the flag is ignored where it does not apply)
+    Xs = ops.Csr.from_dense(X, torch.float32)
+    assert torch.equal(ops.layer_forward(A, Xs, Wt, quant_int8=True, **kw), ops.layer_forward(A, Xs, Wt, **kw))

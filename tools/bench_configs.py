@@ -251,8 +251,27 @@ def main():
             rec[f"ms_layer_fp32_{name}"] = timed(lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, **kw), 50)
             rec[f"ms_layer_fp32_{name}_8bit_quantised"] = timed(
                 lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, **kw), 50)
+            rec[f"ms_layer_fp32_{name}_8bit_int8_operands"] = timed(
+                lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, quant_int8=True, **kw), 50)
         report("c5 in the SGRACE library's setting (float32 buffers, w_qbits 8)", A32, rec, {"f_in": 128, "width": P})
         del A32, X32, D32
+        # the X.W stage of a quantised layer alone on the Reddit shape (232 965 x 602 -> 128): fp32 values on the 8-bit
+        # grid through the fp32 MFMA kernel against integer codes through the int8 matrix cores, with and without the
+        # pass that quantises X (a caller that keeps its features as codes skips it)
+        n, m, p = 232_965, 602, 128
+        Xr = torch.rand((n, m), generator=gen, device=dev)
+        Wr = (torch.rand((p, m), generator=gen, device=dev) * 2 - 1) / p ** 0.5
+        Xq, Wq = ops.fake_quantize(Xr, 0, 8, qc.f_s, qc.f_z), ops.fake_quantize(Wr, 1, 8, qc.w_s, qc.w_z)
+        Xc, _ = ops.quantize_codes_i8(Xr, 0, 8, qc.f_s, qc.f_z)
+        Wc, _ = ops.quantize_codes_i8(Wr, 1, 8, qc.w_s, qc.w_z)
+        rec = {"config": "quantised X.W alone, Reddit shape 232965 x 602 -> 128, 8 bit",
+               "ms_fp32_quantise_X": timed(lambda: ops.fake_quantize(Xr, 0, 8, qc.f_s, qc.f_z, out=Xq), 30),
+               "ms_fp32_xw": timed(lambda: ops.xw_dense(Xq, Wq), 30),
+               "ms_int8_codes_of_X": timed(lambda: ops.quantize_codes_i8(Xr, 0, 8, qc.f_s, qc.f_z), 30),
+               "ms_int8_xw": timed(lambda: ops.xw_dense_i8(Xc, Wc, m, 8, qc.scale_fea, qc.internal_quantization), 30)}
+        rec["x_bytes_fp32"], rec["x_bytes_int8"] = n * m * 4, Xc.numel()
+        print(json.dumps(rec), flush=True)
+        del Xr, Xq, Xc
 
     if "c5" in want and not PMC_LAUNCHES:
         # the same layer on a power-law graph (R-MAT, 2^18 nodes): hub rows take the split path of the plan
