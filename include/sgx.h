@@ -76,14 +76,15 @@ typedef struct sgx_plan sgx_plan;
 int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
                     void *stream);
 /* The same with the cut chosen by the caller: rows over `long_threshold` edges are split into tasks of `chunk`
- * edges (0 = the defaults: 4096 / 4096, which suit the A.H aggregation; the GAT aggregate keeps a softmax state
- * per step and runs best with 512 / 512).  Matrices under 2^20 entries always use 64 / 64. */
+ * edges (0 = the default: both sqrt(nnz) / 2 rounded down to a power of two, 64 .. 4096 -- the measured optimum of the A.H
+ * aggregation moves with the size of the graph; the first stage of the GAT aggregate runs best with 256 / 256).
+ * Matrices under 2^20 entries always use 64 / 64. */
 int sgx_plan_create_ex(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int long_threshold, int chunk,
                        void *stream);
 void sgx_plan_destroy(sgx_plan *plan);
 /* number of rows that take the split path, and the edge count above which a row does (for reports /
- * tests): 4096 by default, 64 for matrices under 2^20 stored entries, whose run time is the longest row's
- * chain of dependent steps */
+ * tests): sqrt(nnz) / 2 as a power of two (at most 4096) by default, 64 for matrices under 2^20 stored entries, whose
+ * run time is the longest row's chain of dependent steps */
 int sgx_plan_long_rows(const sgx_plan *plan);
 int sgx_plan_long_threshold(const sgx_plan *plan);
 /* share of lane-group steps that do work when 8 consecutive rows are packed per wavefront, and
@@ -294,7 +295,9 @@ int sgx_transpose(int dtype, int rows, int cols, const void *in, int64_t ldi,
  * above on each slice of n_feat / n_heads columns with its own vector attention[h][0 : 2*F_head],
  * outputs concatenated -- what n_heads single-head calls on the slices give; E/S are [nnz][n_heads].
  * plan (optional): rows it marks long are cut into edge chunks with per-chunk softmax states that are
- * merged in a fixed order. */
+ * merged in a fixed order.  With a plan (which tells the stored-entry count) the aggregate runs in two stages -- the
+ * softmax weights on the edges, then the A.H aggregation with those weights; sgx_gat_scratch_bytes then includes
+ * nnz * n_heads floats for the weights (S takes them when given). */
 size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan);
 int sgx_gat_aggregate(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads,
                       float alpha,

@@ -120,9 +120,9 @@ extern "C" int sgx_xw_sparse(int dtype, int acc_mode, int spmm_block, int n_rows
                              const void *W_rowmajor, int64_t ldw, void *H, int64_t ldh,
                              const sgx_plan *plan, void *scratch, size_t scratch_bytes, void *stream)
 {
-    // C[r][:] = sum_k Xval[k] * W[Xcol[k]][:]  (K.cpp:2009-2061): the aggregation kernel with the
-    // weight matrix as the gathered table (it fits L2: M_fea x P elements).  (An LDS-resident weight
-    // tile, the literal form of the reference's B_accel, was built and measured slower: DESIGN.md 4.)
+    // C[r][:] = sum_k Xval[k] * W[Xcol[k]][:]  (K.cpp:2009-2061).  From 2^20 entries with a plan that cuts no row: the
+    // weight slice resident in LDS (xw_sparse_lds.hip, the reference's B_accel); otherwise the aggregation kernel with
+    // the weight matrix as the gathered table (it fits L2: M_fea x P elements).  The same sums in the same order.
     return sgx_spmm_launch(dtype, acc_mode, spmm_block, /*relu*/0, n_rows, M_fea, P, rowPtr, columnIndex, values,
                            W_rowmajor, ldw, H, ldh, plan, scratch, scratch_bytes, (hipStream_t)stream, nullptr, nullptr, 0,
                            /*fea_stage*/true);

@@ -103,7 +103,9 @@ def main():
     fetch_all = load(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv"))
     write_all = load(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv"))
     others = {}
-    for label, sub in (("xw_sparse_kernel (X.W, CSR X, layer 1)", "xw_sparse_kernel"), ("xw_dense (X.W, dense X, layer 2)", "xw_dense")):
+    for label, sub in (("xw_sparse_lds_kernel (X.W, CSR X, layer 1, weight slice in LDS)", "xw_sparse_lds_kernel"),
+                       ("xw_sparse_kernel (X.W, CSR X, layer 1, gathered through L2)", "xw_sparse_kernel"),
+                       ("xw_dense (X.W, dense X, layer 2)", "xw_dense")):
         f_, w_ = counter(fetch_all, sub, "FETCH_SIZE"), counter(write_all, sub, "WRITE_SIZE")
         h_, m_ = counter(l2, sub, "TCC_HIT_sum"), counter(l2, sub, "TCC_MISS_sum")
         if f_:
