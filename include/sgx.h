@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 104
+#define SGX_VERSION 105
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -70,15 +70,16 @@ typedef enum sgx_acc_mode { SGX_ACC_F32 = 0, SGX_ACC_REF_HALF = 1 } sgx_acc_mode
  * sblock path (correct, slower on power-law graphs). */
 typedef struct sgx_plan sgx_plan;
 
-/* Builds the plan for rowPtr (device).  Synchronises `stream` once (it has to learn how
- * many long rows there are); not capturable.  n_feat_hint = the P the plan will mostly be
- * used with (sizes the partial-sum scratch it owns). */
+/* Builds the plan for rowPtr (device), on the device (csrc/plan_build.hip): the host reads back the entry count and
+ * then the number of long rows / tasks it has to size arrays for -- 28 bytes, never rowPtr -- so `stream` is
+ * synchronised (three times: twice for those, once before the builder's scratch is freed); not capturable.
+ * n_feat_hint is unused (kept for callers of the first version). */
 int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
                     void *stream);
 /* The same with the cut chosen by the caller: rows over `long_threshold` edges are split into tasks of `chunk`
  * edges (0 = the default: both sqrt(nnz) / 2 rounded down to a power of two, 64 .. 4096 -- the measured optimum of the A.H
  * aggregation moves with the size of the graph; the first stage of the GAT aggregate runs best with 256 / 256).
- * Matrices under 2^20 entries always use 64 / 64. */
+ * Matrices under 2^20 entries always use 64 / 64; a cut above 65536 is taken as 65536. */
 int sgx_plan_create_ex(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int long_threshold, int chunk,
                        void *stream);
 void sgx_plan_destroy(sgx_plan *plan);
@@ -91,6 +92,10 @@ int sgx_plan_long_threshold(const sgx_plan *plan);
  * whether the plan therefore schedules the short rows in degree order instead (1) or not (0) */
 float sgx_plan_natural_utilization(const sgx_plan *plan);
 int sgx_plan_reordered(const sgx_plan *plan);
+/* One of the plan's device arrays copied to dst (device, int32, `capacity` entries) for inspection and tests:
+ * which = 0 long_row, 1 long_first, 2 task_row, 3 task_e0, 4 task_e1, 5 row_order.  Returns the array's length
+ * (dst NULL: the length only) or a negative sgx error. */
+int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream);
 
 /* ---- quantised layer of the SGRACE bitstream (SG.py:53-265, :570-667, :1645-1848) -------
  * The reference quantises inside the device kernel from scale registers and states the arithmetic

@@ -23,7 +23,7 @@ SGX_QUANT_INT8 = 2                                          # sgx_quant.flags: i
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [
     "sgx_plan_create", "sgx_plan_create_ex", "sgx_plan_destroy", "sgx_plan_long_rows", "sgx_plan_long_threshold", "sgx_plan_natural_utilization",
-    "sgx_plan_reordered",
+    "sgx_plan_reordered", "sgx_plan_export",
     "sgx_fake_quantize", "sgx_requantize",
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
     "sgx_spmm_csr", "sgx_spmm_csr_acc", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
@@ -100,6 +100,8 @@ def _load():
     lib.sgx_plan_natural_utilization.restype = ctypes.c_float
     lib.sgx_plan_reordered.argtypes = [vp]
     lib.sgx_plan_reordered.restype = c_int
+    lib.sgx_plan_export.argtypes = [vp, c_int, vp, ctypes.c_int64, vp]
+    lib.sgx_plan_export.restype = ctypes.c_int64
     lib.sgx_fake_quantize.argtypes = [c_int, c_int, ctypes.c_float, ctypes.c_float, c_i64, vp, vp, vp]
     lib.sgx_fake_quantize.restype = c_int
     lib.sgx_requantize.argtypes = [c_int, c_int, c_i64, vp, c_int, c_int, vp]

@@ -5,7 +5,6 @@
 #include "sgx_internal.h"
 
 #include <stdlib.h>
-#include <vector>
 
 namespace {
 
@@ -266,158 +265,7 @@ extern "C" int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_
     return SGX_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Row schedule.  Built on the host from one device->host copy of rowPtr: the graph is fixed
-// across layers and epochs (the reference re-streams the same CSR for every tile and layer),
-// so this runs once per adjacency.
-// ---------------------------------------------------------------------------------------
-// Rows with more edges than the threshold take the split path, in tasks of `chunk` edges.  Measured on the
-// R-MAT S-100M aggregation (threshold = chunk): 512: 2.20 ms, 1024-2048: 2.10, 3072: 2.00, 4096: 1.94,
-// 6144: 2.04, 8192: 2.32 -- a lane group walks a 4096-edge row in 512 steps while the degree-ordered schedule
-// keeps its wavefront full, and every task costs a partial row and a finalize read.  (The GAT aggregate, with
-// its softmax state per step, prefers 512: sgx_plan_create_ex.)
-// The best cut moves with the size of the graph -- a launch of a smaller graph is over before a 4096-edge row's 512
-// dependent steps are (tools/plan_cut_probe.py, R-MAT, cut / ms of the plain aggregate: 2.4 M edges 512 / 0.136 against
-// 4096 / 0.400; 7.5 M edges 1024 / 0.179 against 0.241; 29 M edges 2048 / 0.448 against 0.786; 104 M edges 4096): the
-// optimum follows sqrt(nnz) / 2 rounded down to a power of two, which is what default_cut returns.
-static const int kLongThreshold = 4096;
-static const int kChunk = 4096;
-static int default_cut(int64_t nnz)
-{
-    int cut = 64;
-    while (cut < kLongThreshold && (int64_t)(2 * cut) * (2 * cut) * 4 <= nnz) cut *= 2;      // 2 cut <= sqrt(nnz) / 2
-    return cut;
-}
-// Small matrices finish in microseconds and their time IS the longest row's chain of dependent
-// steps (Cora: 168 edges = 21 steps on one lane group), so there rows are cut much earlier: a
-// 64-edge task is one step for every lane group of its wavefront.
-static const int64_t kSmallNnz = 1 << 20;
-static const int kSmallThreshold = 64, kSmallChunk = 64;
-static const float kReorderBelow = 0.7f; // natural-order lane-group utilisation below which rows are degree-ordered
-
-extern "C" int sgx_plan_create(sgx_plan **out, const int32_t *rowPtr, int n_rows, int n_feat_hint, void *stream)
-{
-    (void)n_feat_hint;
-    return sgx_plan_create_ex(out, rowPtr, n_rows, 0, 0, stream);
-}
-
-extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_rows, int long_threshold_arg, int chunk_arg,
-                                  void *stream)
-{
-    if (!out || !rowPtr) return SGX_ERR_NULL;
-    if (long_threshold_arg < 0 || chunk_arg < 0) return SGX_ERR_SHAPE;
-    if (n_rows < 0) return SGX_ERR_SHAPE;
-    hipStream_t s = (hipStream_t)stream;
-    std::vector<int32_t> rp((size_t)n_rows + 1);
-    SGX_HIP_CHECK(hipMemcpyAsync(rp.data(), rowPtr, sizeof(int32_t) * ((size_t)n_rows + 1), hipMemcpyDeviceToHost, s));
-    SGX_HIP_CHECK(hipStreamSynchronize(s));
-    std::vector<int32_t> long_row, long_first, task_row, task_e0, task_e1;
-    const bool small = rp[(size_t)n_rows] < kSmallNnz;
-    int long_threshold = small ? kSmallThreshold : default_cut(rp[(size_t)n_rows]);
-    int chunk = small ? kSmallChunk : long_threshold;
-    if (!small && long_threshold_arg >= 8) {                          // the caller's cut (large matrices only)
-        long_threshold = long_threshold_arg / 8 * 8;
-        chunk = chunk_arg >= 8 ? chunk_arg / 8 * 8 : long_threshold;
-    }
-    if (const char *t = getenv("SGX_PLAN_LONG_THRESHOLD")) {          // tuning overrides (tools/plan_probe)
-        const int v = atoi(t);
-        if (v >= 8) long_threshold = chunk = v / 8 * 8;
-    }
-    if (const char *t = getenv("SGX_PLAN_CHUNK")) {
-        const int v = atoi(t);
-        if (v >= 8) chunk = v / 8 * 8;
-    }
-    for (int r = 0; r < n_rows; ++r) {
-        const int deg = rp[r + 1] - rp[r];
-        if (deg <= long_threshold) continue;
-        long_row.push_back(r);
-        long_first.push_back((int32_t)task_row.size());
-        for (int e = rp[r]; e < rp[r + 1]; e += chunk) {
-            task_row.push_back(r);
-            task_e0.push_back(e);
-            task_e1.push_back(e + chunk < rp[r + 1] ? e + chunk : rp[r + 1]);
-        }
-    }
-    long_first.push_back((int32_t)task_row.size());
-    sgx_plan *p = new sgx_plan();
-    p->n_rows = n_rows;
-    p->nnz = rp[(size_t)n_rows];
-    p->long_threshold = long_threshold;
-    p->chunk = chunk;
-    p->n_long = (int)long_row.size();
-    p->n_tasks = (int)task_row.size();
-    p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
-    if (p->n_long > 0) {
-        const size_t nl = long_row.size(), nt = task_row.size();
-        int32_t *blob = nullptr;
-        if (hipMalloc(&blob, sizeof(int32_t) * (nl + nl + 1 + 3 * nt)) != hipSuccess) { delete p; return SGX_ERR_HIP; }
-        p->long_row = blob;
-        p->long_first = blob + nl;
-        p->task_row = p->long_first + nl + 1;
-        p->task_e0 = p->task_row + nt;
-        p->task_e1 = p->task_e0 + nt;
-        bool ok = hipMemcpy(p->long_row, long_row.data(), 4 * nl, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(p->long_first, long_first.data(), 4 * (nl + 1), hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(p->task_row, task_row.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(p->task_e0, task_e0.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(p->task_e1, task_e1.data(), 4 * nt, hipMemcpyHostToDevice) == hipSuccess;
-        if (!ok) { (void)hipFree(blob); delete p; return SGX_ERR_HIP; }
-    }
-
-    // Would packing 8 consecutive rows per wavefront keep the lane groups busy?  A group needs
-    // ceil(deg/8) steps, the wavefront runs for the largest of its 8 rows.
-    p->row_order = nullptr;
-    p->n_ordered = 0;
-    {
-        const int kGroup = 8, kStepsMax = long_threshold / 8 + 1;
-        double useful = 0, spent = 0;
-        for (int r0 = 0; r0 < n_rows; r0 += kGroup) {
-            int mx = 0;
-            for (int r = r0; r < r0 + kGroup && r < n_rows; ++r) {
-                const int deg = rp[r + 1] - rp[r];
-                const int steps = deg > long_threshold ? 0 : (deg + 7) / 8;
-                useful += steps;
-                if (steps > mx) mx = steps;
-            }
-            spent += (double)mx * kGroup;
-        }
-        p->natural_utilization = spent > 0 ? (float)(useful / spent) : 1.0f;
-        float reorder_below = kReorderBelow;
-        if (const char *f = getenv("SGX_PLAN_REORDER_BELOW")) reorder_below = (float)atof(f);      // tuning override
-        if (p->natural_utilization < reorder_below && n_rows - p->n_long > 0) {
-            // counting sort by step count, longest first, ascending row id inside a bucket
-            std::vector<int64_t> start(kStepsMax + 1, 0);
-            for (int r = 0; r < n_rows; ++r) {
-                const int deg = rp[r + 1] - rp[r];
-                if (deg <= long_threshold) start[(deg + 7) / 8]++;
-            }
-            int64_t acc = 0;
-            for (int b = kStepsMax; b >= 0; --b) { const int64_t c = start[b]; start[b] = acc; acc += c; }
-            std::vector<int32_t> order((size_t)acc);
-            for (int r = 0; r < n_rows; ++r) {
-                const int deg = rp[r + 1] - rp[r];
-                if (deg <= long_threshold) order[(size_t)start[(deg + 7) / 8]++] = r;
-            }
-            if (hipMalloc(&p->row_order, sizeof(int32_t) * order.size()) != hipSuccess ||
-                hipMemcpy(p->row_order, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice) != hipSuccess) {
-                sgx_plan_destroy(p);
-                return SGX_ERR_HIP;
-            }
-            p->n_ordered = (int)order.size();
-        }
-    }
-    *out = p;
-    return SGX_OK;
-}
-
-extern "C" void sgx_plan_destroy(sgx_plan *plan)
-{
-    if (!plan) return;
-    if (plan->long_row) (void)hipFree(plan->long_row);     // one blob, long_row is its base
-    if (plan->row_order) (void)hipFree(plan->row_order);
-    delete plan;
-}
-
+// ---- accessors of the row schedule (built by plan_build.hip) ----
 extern "C" float sgx_plan_natural_utilization(const sgx_plan *plan) { return plan ? plan->natural_utilization : 1.0f; }
 extern "C" int sgx_plan_reordered(const sgx_plan *plan) { return plan && plan->row_order ? 1 : 0; }
 

@@ -116,6 +116,21 @@ class Plan:
     def reordered(self):
         return bool(lib.sgx_plan_reordered(self._h))
 
+    ARRAYS = ("long_row", "long_first", "task_row", "task_e0", "task_e1", "row_order")
+
+    def export(self, name):
+        """One of the schedule's device arrays (ARRAYS) as an int32 tensor -- for inspection and tests."""
+        which = self.ARRAYS.index(name)
+        n = lib.sgx_plan_export(self._h, which, None, 0, _stream())
+        if n < 0:
+            check(int(n), "sgx_plan_export")
+        out = torch.empty(int(n), dtype=torch.int32, device="cuda")
+        if n:
+            got = lib.sgx_plan_export(self._h, which, _ptr(out), int(n), _stream())
+            if got < 0:
+                check(int(got), "sgx_plan_export")
+        return out
+
     def __del__(self, _destroy=lib.sgx_plan_destroy):        # bound at definition: module globals are gone at shutdown
         h, self._h = getattr(self, "_h", None), None
         if h:
