@@ -109,6 +109,9 @@ int sgx_xw_sparse_lds(int dtype, int n_rows, int m_fea, int n_feat, const int32_
 // rows copied from one pitch to another (util_kernels.hip); dst 16-byte aligned with a pitch that is a multiple of 16
 int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_pitch, int row_bytes, int64_t n_rows,
                      hipStream_t stream);
+// X.W, fp16, long K, the weight tile resident in LDS (xw_dense_wlds.hip); SGX_ERR_UNSUPPORTED = not its shape
+int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                      int h_aligned, int relu, hipStream_t stream);
 int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                     const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep, int relu = 0);
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,

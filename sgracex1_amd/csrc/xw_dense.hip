@@ -517,6 +517,9 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     static const bool no_lds = getenv("SGX_XW_NO_LDS") != nullptr;
     const bool tall = n_rows >= 32768 && !short_tiles;
     if (dtype == SGX_F16 && tall && !no_lds && M_fea > 128) {
+        // all of W^T in LDS, X streamed through a register ring (xw_dense_wlds.hip): 602 -> 128 on 233 K rows
+        const int rc = sgx_xw_dense_wlds(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, relu, s);
+        if (rc != SGX_ERR_UNSUPPORTED) return rc;
         const dim3 grid((unsigned)((n_rows + kLdsBM - 1) / kLdsBM), (unsigned)((ldh + kLdsBN - 1) / kLdsBN));
         hipLaunchKernelGGL(xw_dense_lds_f16_kernel, grid, dim3(kBlock), 0, s, n_rows, M_fea, P, (const f16 *)X, ldx,
                            (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, relu);

@@ -610,6 +610,41 @@ def test_xw_dense_tall_tiles(dtype, M, P):
     assert not base[:, P:].any()
 
 
+@pytest.mark.parametrize("M,P", [(602, 128), (602, 256), (300, 128), (130, 16), (1000, 64), (2000, 40), (601, 128), (608, 41)])
+def test_xw_dense_weights_in_lds(M, P):
+    """Long K with all of W^T resident in LDS and X streamed through a register ring (xw_dense_wlds.hip) against the
+    128 x 128 tile kernel it replaces: the same k-steps into the same MFMA in the same order, so the same bits -- one or
+    two column blocks, 2 / 4 / 8 column tiles, K a multiple of 32 or not, odd K (2-byte aligned rows: stays with the
+    tile kernel), a ragged last row tile.  Rows of NaN / Inf stay in their rows: a row's last k-step reads into the
+    next row and is masked."""
+    import os
+    from sgracex1_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 7 + P)
+    n = 33_000 + 13
+    X = (torch.rand((n, M), generator=g, device="cuda") - 0.4).half()
+    Wt = ((torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5).half()
+    bad = torch.tensor([1, 17, 4095, 20_000, n - 1], device="cuda")
+    X[bad] = float("nan")
+    X[bad + 0, 0] = float("inf")
+    got = ops.xw_dense(X, Wt)
+    act = ops.xw_dense(X, Wt, relu=True)
+    os.environ["SGX_XW_NO_WLDS"] = "1"
+    try:
+        tile = ops.xw_dense(X, Wt)
+    finally:
+        del os.environ["SGX_XW_NO_WLDS"]
+    ok = torch.ones(n, dtype=torch.bool, device="cuda")
+    ok[bad] = False
+    assert torch.equal(got[ok], tile[ok]) and torch.isfinite(got[ok].float()).all()
+    assert torch.isnan(got[~ok].float()).all()
+    want = X[ok].float() @ Wt.float().t()
+    torch.testing.assert_close(got[ok].float(), want, rtol=2e-3, atol=2e-3)
+    assert torch.equal(act[ok], torch.where(got[ok] > 0, got[ok], torch.zeros_like(got[ok])))
+    base = got._base if got._base is not None else got
+    assert not base[ok][:, P:].any()
+
+
 @pytest.mark.parametrize("dtype,F", [(torch.float16, 128), (torch.float16, 256), (torch.float16, 250), (torch.float32, 100),
                                      (torch.float32, 256)])
 def test_gat_wide_rows_low_degree(oracle, dtype, F):
