@@ -123,3 +123,39 @@ def test_gat_backward_edge_pass_matches_dense_formulas(F, vdtype):
     Whp[:, :F] = Wh
     sg2, g12 = ops.gat_backward_edges(A, E, S, G, Whp[:, :F], alpha)
     assert torch.equal(sg2, sg) and torch.equal(g12, g1)
+
+
+@pytest.mark.parametrize("F", [64, 256])
+def test_gat_backward_edge_pass_power_law(F):
+    """The edge pass on a heavy-tailed graph -- hub rows of thousands of entries (taken by whole wavefronts in the row
+    kernel), rows without entries, an entry count that is not a multiple of the dots kernel's 256 -- against the same
+    formulas on the edge list in float64."""
+    from sgracex1_amd import graphs, ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(F)
+    A = graphs.rmat_graph_n(30_011, 900_000, seed=F, self_loops=False)
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    assert int(deg.max()) > 2000 and int((deg == 0).sum()) > 0 and A.nnz % 256 != 0
+    n, alpha = A.n_rows, 0.2
+    val = A.val.float()
+    val[torch.rand(A.nnz, generator=g, device=dev) < 0.01] = -0.5             # stored, masked out
+    A = ops.Csr(A.rowptr, A.col, val.half(), A.n_cols)
+    Wh = torch.randn((n, F), generator=g, device=dev).half().float()
+    att = (torch.randn(2 * F, generator=g, device=dev) * (0.5 / F ** 0.5)).half()
+    G = torch.randn((n, F), generator=g, device=dev)
+    _out, E, S = ops.gat_aggregate(A, Wh.half(), att, alpha=alpha, want_edge_outputs=True)
+    sg, g1 = ops.gat_backward_edges(A, E, S, G, Wh, alpha)
+    row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    colj = A.col.long()
+    d = (G.double()[row] * Wh.double()[colj]).sum(1)
+    dx = S.double() * d
+    rs = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, dx)
+    want = dx - S.double() * rs[row]
+    want = torch.where(A.val.float() > 0, want, torch.zeros_like(want))
+    want = torch.where(E > 0, want, alpha * want)
+    want_g1 = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, want)
+    scale = float(want.abs().max())
+    assert torch.allclose(sg.double(), want, rtol=2e-4, atol=2e-5 * scale)
+    assert torch.allclose(g1.double(), want_g1, rtol=2e-4, atol=2e-4 * scale)
+    assert not g1[deg == 0].any()
