@@ -18,8 +18,8 @@
 //          coincide: L1), then each wavefront walks its 64 entries 64 / LPR at a time, LPR lanes per entry, and
 //          parks dx_e = S_e d_e in sg.  The entry count comes from rowPtr[n_rows] on the device (persistent grid):
 //          the host never reads it.
-//   rows   8 lanes per row: the row sum of dx, then sg_e and g1; rows over 256 entries are taken by their whole
-//          wavefront afterwards, 64 entries per step.
+//   rows   8 lanes per row: the row sum of dx, then sg_e and g1; rows over 256 entries are left to a third launch in
+//          which a workgroup of 1024 takes each of them (a hub row of 20 K entries by one wavefront was 0.4 ms).
 #include "sgx_device.h"
 
 namespace {
@@ -120,21 +120,61 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(
         for (int off = 1; off < kRowLanes; off <<= 1) acc += __shfl_xor(acc, off);
         if (live && sub == 0) g1[r] = acc;
     }
-    // the long rows of this wavefront, one after the other, all 64 lanes on each
-    unsigned long long todo = __ballot(is_long && sub == 0);
-    while (todo) {
-        const int owner = __ffsll((long long)todo) - 1;
+}
+
+// rows over kRowLong entries: a workgroup of 1024 looks at 64 consecutive rows and takes the long ones among them one
+// after the other with all its threads (most workgroups find none and leave after reading 65 row pointers)
+constexpr int kLongThreads = 1024;
+template <typename TV>
+__global__ __launch_bounds__(kLongThreads) void gat_bwd_long_rows_kernel(
+    int n_rows, const int32_t *__restrict__ rowptr, const TV *__restrict__ val, const float *__restrict__ E,
+    const float *__restrict__ S, float alpha, float *__restrict__ sg, float *__restrict__ g1)
+{
+    __shared__ float part[kLongThreads / 64];
+    __shared__ float total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r_first = (int64_t)blockIdx.x * 64;
+    auto block_sum = [&](float v) -> float {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        __syncthreads();                              // `total` of the previous sum has been read by everyone
+        if (lane == 0) part[wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (int i = 0; i < kLongThreads / 64; ++i) t += part[i];
+            total = t;
+        }
+        __syncthreads();
+        return total;
+    };
+    // which of the 64 rows are long: one look by the first wavefront
+    __shared__ unsigned long long long_mask;
+    if (wave == 0) {
+        const int64_t r = r_first + lane;
+        const int deg = r < n_rows ? rowptr[r + 1] - rowptr[r] : 0;
+        const unsigned long long m = __ballot(deg > kRowLong);
+        if (lane == 0) long_mask = m;
+    }
+    __syncthreads();
+    unsigned long long todo = long_mask;
+    while (todo) {                                    // (uniform over the workgroup)
+        const int64_t r = r_first + (__ffsll((long long)todo) - 1);
         todo &= todo - 1;
-        const int le0 = __shfl(e0, owner), le1 = __shfl(e1, owner);
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
         float rs = 0.0f;
-        for (int idx = le0 + lane; idx < le1; idx += 64) rs += sg[idx];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) rs += __shfl_xor(rs, off);
+        for (int idx = e0 + (int)threadIdx.x; idx < e1; idx += kLongThreads) rs += sg[idx];
+        rs = block_sum(rs);
         float acc = 0.0f;
-        for (int idx = le0 + lane; idx < le1; idx += 64) acc += finish(idx, rs);
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
-        if (lane == owner) g1[r] = acc;
+        for (int idx = e0 + (int)threadIdx.x; idx < e1; idx += kLongThreads) {
+            float v = sg[idx] - S[idx] * rs;
+            if (!(Elem<TV>::to_f32(val[idx]) > 0.0f)) v = 0.0f;
+            if (!(E[idx] > 0.0f)) v *= alpha;
+            sg[idx] = v;
+            acc += v;
+        }
+        acc = block_sum(acc);
+        if (threadIdx.x == 0) g1[r] = acc;
     }
 }
 
@@ -206,6 +246,12 @@ extern "C" int sgx_gat_backward_edges(int dtype_values, int n_rows, int n_cols, 
         hipLaunchKernelGGL(gat_bwd_rows_kernel<f16>, dim3(grid), dim3(kBlock), 0, s, n_rows, rowPtr, (const f16 *)values, E, S, alpha, sg, g1);
     else
         hipLaunchKernelGGL(gat_bwd_rows_kernel<float>, dim3(grid), dim3(kBlock), 0, s, n_rows, rowPtr, (const float *)values, E, S, alpha, sg, g1);
+    SGX_LAUNCH_CHECK();
+    const unsigned grid_long = (unsigned)((n_rows + 63) / 64);
+    if (dtype_values == SGX_F16)
+        hipLaunchKernelGGL(gat_bwd_long_rows_kernel<f16>, dim3(grid_long), dim3(kLongThreads), 0, s, n_rows, rowPtr, (const f16 *)values, E, S, alpha, sg, g1);
+    else
+        hipLaunchKernelGGL(gat_bwd_long_rows_kernel<float>, dim3(grid_long), dim3(kLongThreads), 0, s, n_rows, rowPtr, (const float *)values, E, S, alpha, sg, g1);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }

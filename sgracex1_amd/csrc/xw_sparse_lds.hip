@@ -78,21 +78,42 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     const int c_base = split * CP;
 
     // ---- the slice of W into LDS (rows [0, m_fea), then one zero row) ----
-    for (int i = threadIdx.x; i < (m_fea + 1) * LPR; i += kThreads) {
-        const int r = i / LPR, c0 = c_base + (i % LPR) * VEC;
-        union { u32x4 v; T e[VEC]; } u;
-        u.v = u32x4{0u, 0u, 0u, 0u};
-        if (r < m_fea) {
-            const T *src = W + (int64_t)r * ldw + c0;
-            if (w_vec && c0 + VEC <= ldw) {
-                u.v = *reinterpret_cast<const u32x4 *>(src);
-            } else {
+    if (w_vec) {
+        // kFill chunks per thread are requested before the first is stored (one at a time is a round trip to L2 per
+        // chunk, six in a row at the Cora shape); out-of-range offsets where there is nothing to load (the zero row,
+        // chunks past the last row of the slice): zeros, and the same number of requests on every path
+        constexpr int kFill = 6;
+        const int total = (m_fea + 1) * LPR;
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T *>(W), 0, (unsigned)(((int64_t)(m_fea - 1) * ldw + ldw) * (int64_t)sizeof(T)), 0x00020000);
+        for (int i0 = threadIdx.x; i0 < total; i0 += kThreads * kFill) {
+            u32x4 v[kFill];
+#pragma unroll
+            for (int f = 0; f < kFill; ++f) {
+                const int i = i0 + kThreads * f;
+                const int r = i / LPR, c0 = c_base + (i % LPR) * VEC;
+                const bool in = i < total && r < m_fea && c0 + VEC <= ldw;
+                v[f] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, in ? (unsigned)(((int64_t)r * ldw + c0) * (int64_t)sizeof(T)) : kOOB, 0, 0);
+            }
+#pragma unroll
+            for (int f = 0; f < kFill; ++f) {
+                const int i = i0 + kThreads * f;
+                if (i < total) *reinterpret_cast<u32x4 *>(lds + (size_t)i * 16) = v[f];
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < (m_fea + 1) * LPR; i += kThreads) {
+            const int r = i / LPR, c0 = c_base + (i % LPR) * VEC;
+            union { u32x4 v; T e[VEC]; } u;
+            u.v = u32x4{0u, 0u, 0u, 0u};
+            if (r < m_fea) {
+                const T *src = W + (int64_t)r * ldw + c0;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j)
                     if (c0 + j < n_feat) u.e[j] = src[j];
             }
+            *reinterpret_cast<u32x4 *>(lds + (size_t)i * 16) = u.v;
         }
-        *reinterpret_cast<u32x4 *>(lds + (size_t)i * 16) = u.v;
     }
     __syncthreads();
 
