@@ -991,6 +991,8 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
             }
         }
         if (alone && h == 0) dead[r] = l > 0.0f ? 0 : 1;
+    } else if (alone && h == 0) {
+        dead[r] = 1;             // a wavefront whose rows are all empty: they are rows without a live edge all the same
     }
 
     // the longer rows of this wavefront, one at a time with every lane: a lane per edge, the heads (8 at a time) in its

@@ -673,3 +673,48 @@ def test_gat_wide_rows_low_degree(oracle, dtype, F):
     np.testing.assert_allclose(E.cpu().numpy(), wE, rtol=2e-3, atol=2e-3)
     one_chunk = ops.gat_aggregate(A, Wh, att, relu=True, use_plan=False)
     assert torch.allclose(got.float(), one_chunk.float(), rtol=2e-3 if dtype == torch.float16 else 1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,heads,F", [(torch.float16, 1, 256), (torch.float16, 8, 256), (torch.float16, 1, 64), (torch.float16, 4, 128),
+                                           (torch.float32, 1, 64), (torch.float32, 8, 256), (torch.float16, 3, 96)])
+@pytest.mark.parametrize("gen_name", ["uniform", "rmat"])
+def test_gat_two_stage_with_and_without_edge_outputs(oracle, dtype, heads, F, gen_name):
+    """The two-stage GAT aggregate with and without the E / S side outputs (the weights land in the caller's S or in
+    scratch): the same rows bit for bit -- short rows, rows taken by a whole wavefront, hub rows cut into tasks, masked
+    edges, rows without a live edge (R-MAT without self loops leaves thousands of empty rows) -- and inside the band of
+    the oracle."""
+    from sgracex1_amd import graphs, ops
+    n = 40_000
+    A = (graphs.rmat_graph_n if gen_name == "rmat" else graphs.uniform_graph)(n, 1_300_000, seed=F + heads, dtype=dtype,
+                                                                               self_loops=(gen_name == "uniform"))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(heads * 1000 + F)
+    val = A.val.float()
+    val[torch.rand(A.nnz, generator=g, device="cuda") < 0.02] = -0.25          # stored, masked out
+    A = ops.Csr(A.rowptr, A.col, val.to(dtype), A.n_cols)
+    if gen_name == "rmat":
+        assert A.gat_plan.long_rows > 0 and int((A.rowptr[1:] == A.rowptr[:-1]).sum()) > 0
+    Wh = (torch.randn((n, F), generator=g, device="cuda") * 0.5).to(dtype)
+    att = (torch.randn(heads * 2 * (F // heads), generator=g, device="cuda") * (0.5 / (F // heads) ** 0.5)).to(dtype)
+    junk = torch.full((20_000_000,), float("nan"), device="cuda")              # what the allocator hands out next is not zeros
+    del junk
+    fly = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
+    with_edges, _E, S = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads, want_edge_outputs=True)
+    assert torch.equal(fly, with_edges)
+    # rows without a live edge receive the mean row of Wh (the dense emulation's rule, SG.py:638-641) -- every one of
+    # them, whichever kernel of stage A met it (a wavefront of empty rows once left their flags unwritten)
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    live = torch.zeros(n, dtype=torch.int64, device="cuda").index_add_(0, row, (A.val.float() > 0).long()) > 0
+    if (~live).any():
+        mean_row = torch.relu(Wh.float().mean(0))
+        for got in (fly, with_edges):
+            torch.testing.assert_close(got[~live].float(), mean_row.expand(int((~live).sum()), F), rtol=1e-2, atol=2e-3)
+    if heads == 1:
+        csr = (A.rowptr.cpu().numpy(), A.col.cpu().numpy(), A.val.float().cpu().numpy())
+        want, _wE, wS = oracle.gat_f64(1, csr, Wh.float().cpu().numpy(), att.float().cpu().numpy(), 0.2)
+        tol = dict(rtol=1e-2, atol=2e-3) if dtype == torch.float16 else dict(rtol=2e-4, atol=2e-5)
+        # rows with a live edge (the stored-edge oracle does not restate the dead-row rule)
+        lv = live.cpu().numpy()
+        np.testing.assert_allclose(fly.float().cpu().numpy()[lv], want[lv], **tol)
+        np.testing.assert_allclose(S.cpu().numpy()[lv[row.cpu().numpy()]], wS[lv[row.cpu().numpy()]], rtol=4e-3, atol=1e-5)
