@@ -327,6 +327,88 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The same weights-stationary form in fp32 (the SGRACE library's own setting runs float32 buffers, SG.py:1645-1848):
+// a wavefront keeps the fragments of NTW column tiles for all of K <= 128 in registers (KB blocks of 16 k x NTW tiles x
+// 4 VGPRs <= 128), walks 16-row tiles of X persistently with the next tile's fragments requested before this tile's
+// MFMAs, and sums in the order of xw_dense_f32_kernel (k blocks ascending, element j of a lane's four ascending), so the
+// two kernels give the same bits.  The tile kernel re-reads its W fragments from L1 / L2 every k-step:
+// 128 -> 256 on 169 K rows 0.184 ms against an MFMA floor of 0.07 ms (v_mfma_f32_16x16x4_f32 is the fp32 peak's 157 TF/s).
+// ---------------------------------------------------------------------------------------
+template <int KB, int NTW>
+__global__ __launch_bounds__(kBlock) void xw_dense_stationary_f32_kernel(
+    int n_rows, int M, int P, int col_groups, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt,
+    int64_t ldw, float *__restrict__ H, int64_t ldh, int x_aligned, int w_aligned, int h_aligned, sgx_epilogue ep, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t total_waves = (int64_t)gridDim.x * (kBlock / 64);
+    const int cg = (int)(gw % col_groups);
+    const int64_t stream = gw / col_groups, n_streams = total_waves / col_groups;
+    if (stream >= n_streams) return;                            // leftover wavefronts of the last workgroup
+    const int n_base = cg * NTW * 16;
+
+    f32x4 a[KB][NTW];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = n_base + nt * 16 + l15;
+            a[kb][nt] = load_k4(Wt + (int64_t)n * ldw, kb * 16 + 4 * lq, M, n < P, w_aligned);
+        }
+
+    const int64_t n_tiles = ((int64_t)n_rows + 15) / 16;
+    f32x4 b[KB], b_next[KB];
+    int64_t tile = stream;
+    if (tile < n_tiles) {
+        const int64_t m = tile * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) b_next[kb] = load_k4(X + m * ldx, kb * 16 + 4 * lq, M, m < n_rows, x_aligned);
+    }
+    for (; tile < n_tiles; tile += n_streams) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) b[kb] = b_next[kb];
+        const int64_t next = tile + n_streams;
+        if (next < n_tiles) {
+            const int64_t m = next * 16 + l15;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) b_next[kb] = load_k4(X + m * ldx, kb * 16 + 4 * lq, M, m < n_rows, x_aligned);
+        }
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb][nt][j], b[kb][j], acc[nt], 0, 0, 0);
+        const int64_t m = tile * 16 + l15;
+        if (m >= n_rows) continue;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = n_base + nt * 16 + 4 * lq;
+            float *dst = H + m * ldh + n;
+            if (ep.rq_ten_pow != 0.0f) {                       // quantised layer: H is re-quantised as it is produced
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][j] = sgx_requant_value(acc[nt][j], ep);
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][j] = acc[nt][j] > 0.0f ? acc[nt][j] : 0.0f;
+            }
+            if (h_aligned && n + 4 <= ldh) {
+                *reinterpret_cast<f32x4 *>(dst) = acc[nt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < ldh) dst[j] = acc[nt][j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Long K (fp16, M_fea > 128) on many rows: a workgroup computes 128 rows x 128 columns, its four wavefronts 64 x 64
 // each.  The k-steps' operand tiles (128 x 32 halves of X and of Wt) go through LDS, double buffered: the global
 // loads of step s+1 are in flight (16 bytes per lane, whole 64-byte row pieces per 4 lanes) while the MFMAs of step s
@@ -455,6 +537,40 @@ int try_stationary(int n_rows, int M, int P, const void *X, int64_t ldx, const v
 #undef SGX_ST
 }
 
+template <int KB, int NTW>
+int launch_stationary_f32(int n_rows, int M, int P, int nt_total, const void *X, int64_t ldx, const void *Wt, int64_t ldw,
+                          void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
+{
+    const int groups = (nt_total + NTW - 1) / NTW;
+    const int64_t n_tiles = ((int64_t)n_rows + 15) / 16;
+    // persistent grid: 2 workgroups per CU (some 200 VGPRs per lane), trimmed to the work there is, whole column-group sets only
+    int64_t waves = (int64_t)256 * 2 * (kBlock / 64);
+    if (waves > n_tiles * groups) waves = n_tiles * groups;
+    waves = (waves + groups - 1) / groups * groups;
+    const unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL((xw_dense_stationary_f32_kernel<KB, NTW>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
+                       (const float *)X, ldx, (const float *)Wt, ldw, (float *)H, ldh, xa, wa, ha, ep, relu);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+// picks (KB, NTW) for the fp32 stationary kernel; SGX_ERR_UNSUPPORTED = use the tile kernel
+int try_stationary_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                       int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
+{
+    if (M > 128 || n_rows < 8192 || getenv("SGX_XW_NO_STATIONARY_F32")) return SGX_ERR_UNSUPPORTED;      // (tuning / test override)
+    // the workgroup's 4 wavefronts take the column groups of the same row tile when there are 4 of them (X from L1 then)
+    const int nt_total = (int)((ldh + 15) / 16);               // pad columns P..ldh-1 are produced (as zeros) too
+    const int kb = (M + 15) / 16;
+#define SGX_ST32(KB_, NTW_) return launch_stationary_f32<KB_, NTW_>(n_rows, M, P, nt_total, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu)
+    if (kb <= 2) { if (nt_total >= 4) SGX_ST32(2, 4); if (nt_total >= 2) SGX_ST32(2, 2); SGX_ST32(2, 1); }
+    if (kb <= 4) { if (nt_total >= 4) SGX_ST32(4, 4); if (nt_total >= 2) SGX_ST32(4, 2); SGX_ST32(4, 1); }
+    if (nt_total >= 4) SGX_ST32(8, 4);
+    if (nt_total >= 2) SGX_ST32(8, 2);
+    SGX_ST32(8, 1);
+#undef SGX_ST32
+}
+
 template <int NT, int MT>
 int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
                 int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
@@ -511,6 +627,9 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     // (the LDS kernel below loses to this one on short K: 100 -> 256 on 2.4 M rows 0.78 vs 0.52 ms, 64 -> 64 0.29 vs 0.22 ms)
     if (dtype == SGX_F16) {
         const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
+        if (rc != SGX_ERR_UNSUPPORTED) return rc;
+    } else {
+        const int rc = try_stationary_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
     static const bool short_tiles = getenv("SGX_XW_SHORT_TILES") != nullptr;      // tuning override, read once

@@ -718,3 +718,29 @@ def test_gat_two_stage_with_and_without_edge_outputs(oracle, dtype, heads, F, ge
         lv = live.cpu().numpy()
         np.testing.assert_allclose(fly.float().cpu().numpy()[lv], want[lv], **tol)
         np.testing.assert_allclose(S.cpu().numpy()[lv[row.cpu().numpy()]], wS[lv[row.cpu().numpy()]], rtol=4e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,P", [(128, 256), (100, 47), (64, 64), (7, 21), (33, 300), (16, 16), (128, 8)])
+def test_xw_dense_fp32_weights_in_registers(M, P):
+    """fp32 X.W with K <= 128 on 8 K rows and more: the weights-stationary kernel (W fragments in registers, X streamed)
+    against the tile kernel it replaces -- same sums in the same order, so the same bits -- and against torch in fp32;
+    with the ReLU on the stores; ragged last tile, pad columns zero."""
+    import os
+    from sgracex1_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 13 + P)
+    n = 20_000 + 11
+    X = torch.rand((n, M), generator=g, device="cuda") - 0.4
+    Wt = (torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5
+    got = ops.xw_dense(X, Wt)
+    act = ops.xw_dense(X, Wt, relu=True)
+    os.environ["SGX_XW_NO_STATIONARY_F32"] = "1"
+    try:
+        tile = ops.xw_dense(X, Wt)
+    finally:
+        del os.environ["SGX_XW_NO_STATIONARY_F32"]
+    assert torch.equal(got, tile)
+    torch.testing.assert_close(got, X @ Wt.t(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(act, torch.where(got > 0, got, torch.zeros_like(got)))
+    base = got._base if got._base is not None else got
+    assert not base[:, P:].any()
