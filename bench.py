@@ -252,6 +252,12 @@ def device_identity(torch, device):
     return " ".join(str(x) for x in parts)
 
 
+def note(msg):
+    """progress on stderr (SGX_BENCH_VERBOSE=1): where a multi-rank rehearsal is when it is slow or stuck"""
+    if os.environ.get("SGX_BENCH_VERBOSE"):
+        print(f"[bench {os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     import torch
@@ -295,6 +301,7 @@ def main():
     exchange = args.exchange or ("allgather" if args.cut >= 0.5 else "halo-overlap")
     n, hidden = wl["n"], wl["hidden"]
     nnz = A.nnz
+    note(f"graph ready: {n} rows, {nnz} stored entries")
     A.plan  # build the row schedules outside the timed region (once per graph)
     if isinstance(X, ops.Csr):
         X.plan
@@ -382,6 +389,7 @@ def main():
 
     # warm-up; for N > 1 it doubles as the trial of the overlapped exchange: should that path raise on this
     # node, every rank drops to the one-pass halo exchange together (same structures) instead of losing the run
+    note("structures ready; warm-up")
     failed = 0
     try:
         for _ in range(args.warmup):
@@ -402,11 +410,13 @@ def main():
             for _ in range(args.warmup):
                 step(0, False)
     barrier()
+    note("timed steps")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    note(f"timed steps done: {elapsed:.3f} s")
     if world > 1:
         red_dev = device if dist.get_backend() == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -450,7 +460,9 @@ def main():
             def exchange_once():
                 sdist.all_gather_into(table, D1)
             what = f"{coll} all-gather of H"
+        note("exchange alone")
         x_ms = time_alone(exchange_once)
+        note(f"exchange alone: {x_ms:.2f} ms; all-gather forms")
         exchange_stats = {"what": what, "rows_received_per_rank_per_layer": recv_rows,
                           "bytes_received_per_rank_per_layer": recv_rows * row_bytes,
                           "max_bytes_per_link_per_layer": link_rows * row_bytes, "ms_alone_per_layer": x_ms,
@@ -460,7 +472,9 @@ def main():
         # library's all-gather and as one batch of point-to-point transfers (one per link of the fully connected node)
         full = table if halo is None else torch.empty((n * world, hidden), dtype=torch.float16, device=device)
         ag_ms = time_alone(lambda: sdist.all_gather_into(full, D1), rounds=3)
+        note(f"all_gather_into_tensor: {ag_ms:.2f} ms; point-to-point batch")
         p2p_ms = time_alone(lambda: sdist.all_gather_direct(full, D1, bounds, rank), rounds=3)
+        note(f"point-to-point batch: {p2p_ms:.2f} ms")
         per_link = n * row_bytes
         allgather_stats = {"what": f"all-gather of H [{n * world} x {hidden}] f16 alone, {world} ranks over {coll}",
                            "bytes_received_per_rank_per_layer": n * (world - 1) * row_bytes, "bytes_per_link_per_layer": per_link,
