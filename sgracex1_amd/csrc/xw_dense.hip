@@ -629,7 +629,9 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     } else {
-        const int rc = try_stationary_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
+        int rc = sgx_xw_dense_wlds_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, ha, ep, relu, s);
+        if (rc != SGX_ERR_UNSUPPORTED) return rc;
+        rc = try_stationary_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
     static const bool short_tiles = getenv("SGX_XW_SHORT_TILES") != nullptr;      // tuning override, read once

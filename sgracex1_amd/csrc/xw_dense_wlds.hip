@@ -35,6 +35,7 @@ constexpr int kMT = 2;                     // 16-row tiles of X per wavefront ti
 constexpr size_t kWldsLds = 160 * 1024;
 
 typedef f16x8 f16x8_u2 __attribute__((aligned(2)));
+typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
 
 __device__ __forceinline__ f16 relu_half(f16 v, int relu) { return (!relu || v > (f16)0) ? v : (f16)0; }
 
@@ -294,4 +295,175 @@ int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, cons
     case 4: return launch_wlds<4>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, relu, n_cb, LP, KS, stream);
     default: return launch_wlds<8>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, relu, n_cb, LP, KS, stream);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// fp32, K <= 128, wide outputs: all of W^T in LDS (256 x 128 floats = 128 KB, rows of K_pad + 4 floats so that the
+// 16-byte fragment reads of 16 consecutive rows fall into 16 different bank groups), every wavefront computes ALL
+// column tiles of its 16-row tiles -- X is read once, not once per column group as in the register-stationary kernel
+// (xw_dense.hip), and a tile is 128 LDS reads + 512 MFMAs (16 K cycles of v_mfma_f32_16x16x4_f32) behind which the
+// next tile's 8 KB of X arrive.  fp32 X.W is MFMA-bound (157 TF/s): 128 -> 256 on 169 K rows has a floor of 0.07 ms.
+// Sums in the order of xw_dense_f32_kernel (k blocks ascending, element j of a lane's four ascending): the same bits.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kW32Threads = 512;
+
+template <int KB, int NT>
+__global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
+    int n_rows, int M, int P, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt, int64_t ldw,
+    float *__restrict__ H, int64_t ldh, int x_aligned, int h_aligned, sgx_epilogue ep, int relu)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw32[];
+    float *sW = reinterpret_cast<float *>(lds_raw32);            // [16 NT][LP]
+    constexpr int LP = 16 * KB + 4;                              // floats per LDS row: (LP / 4) odd
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // W^T into LDS, 8 chunks of 16 bytes per thread requested at a time; zero outside W
+    {
+        constexpr int kFill = 8;
+        constexpr int cpr = LP / 4, total = 16 * NT * cpr;
+        const __amdgpu_buffer_rsrc_t w_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0, (unsigned)(((int64_t)(P - 1) * ldw + M) * 4), 0x00020000);
+        for (int c0 = tid; c0 < total; c0 += kW32Threads * kFill) {
+            u32x4 v[kFill];
+            int kk[kFill];
+#pragma unroll
+            for (int u = 0; u < kFill; ++u) {
+                const int c = c0 + kW32Threads * u;
+                const int n = c / cpr, k = 4 * (c - n * cpr);
+                kk[u] = k;
+                const bool in = c < total && n < P && k < M;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, in ? (unsigned)(((int64_t)n * ldw + k) * 4) : kOOB, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kFill; ++u) {
+                const int c = c0 + kW32Threads * u;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) v[u][d] = kk[u] + d < M ? v[u][d] : 0u;
+                if (c < total) *reinterpret_cast<u32x4 *>(lds_raw32 + (size_t)c * 16) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int64_t n_tiles = ((int64_t)n_rows + 15) / 16;
+    const int64_t gw = (int64_t)blockIdx.x * (kW32Threads / 64) + (tid >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kW32Threads / 64);
+    auto load_x = [&](int64_t tile, f32x4 (&b)[KB]) {
+        const int64_t m = tile * 16 + l15;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int k = kb * 16 + 4 * lq;
+            f32x4 v = {0, 0, 0, 0};
+            if (m < n_rows) {
+                const float *row = X + m * ldx;
+                if (k + 4 <= M) {
+                    v = *reinterpret_cast<const f32x4_u4 *>(row + k);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < M) v[j] = row[k + j];
+                }
+            }
+            b[kb] = v;
+        }
+    };
+    f32x4 b[KB], b_next[KB];
+    int64_t tile = gw;
+    if (tile < n_tiles) load_x(tile, b_next);
+    const float *w_lane = sW + (size_t)l15 * LP + 4 * lq;
+    for (; tile < n_tiles; tile += n_waves) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) b[kb] = b_next[kb];
+        if (tile + n_waves < n_tiles) load_x(tile + n_waves, b_next);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0, 0, 0, 0};
+        // (column tiles 8 at a time: the fragments of all 16 at once do not fit beside the sums and two tiles of X)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += 8) {
+                f32x4 a[8];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) a[nt] = *reinterpret_cast<const f32x4 *>(w_lane + (size_t)(16 * (n0 + nt)) * LP + 16 * kb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+                        acc[n0 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][j], b[kb][j], acc[n0 + nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);       // (or hipcc hoists the LDS reads of all 16 blocks: 512 VGPRs of fragments)
+            }
+        }
+        const int64_t m = tile * 16 + l15;
+        if (m >= n_rows) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + 4 * lq;
+            float *dst = H + m * ldh + n;
+            if (ep.rq_ten_pow != 0.0f) {                       // quantised layer: H is re-quantised as it is produced
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][j] = sgx_requant_value(acc[nt][j], ep);
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][j] = acc[nt][j] > 0.0f ? acc[nt][j] : 0.0f;
+            }
+            if (h_aligned && n + 4 <= ldh) {
+                *reinterpret_cast<f32x4 *>(dst) = acc[nt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < ldh) dst[j] = acc[nt][j];
+            }
+        }
+    }
+}
+
+template <int KB, int NT>
+int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh, int xa,
+                    int ha, sgx_epilogue ep, int relu, hipStream_t s)
+{
+    auto kernel = xw_dense_wlds_f32_kernel<KB, NT>;
+    const size_t lds_bytes = (size_t)16 * NT * (16 * KB + 4) * 4;
+    static bool attr_set = false;                     // per instantiation
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWldsLds) !=
+            hipSuccess)
+            return SGX_ERR_HIP;
+        attr_set = true;
+    }
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    const int64_t tiles = ((int64_t)n_rows + 15) / 16;
+    int64_t grid = cus;                               // one workgroup per CU (the table takes most of its LDS)
+    const int64_t want = (tiles + kW32Threads / 64 - 1) / (kW32Threads / 64);
+    if (want < grid) grid = want;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kW32Threads), lds_bytes, s, n_rows, M, P, (const float *)X, ldx,
+                       (const float *)Wt, ldw, (float *)H, ldh, xa, ha, ep, relu);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
+}  // namespace
+
+// SGX_ERR_UNSUPPORTED: not this kernel's shape (the caller goes on to the register-stationary and tile kernels)
+int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                          int x_aligned, int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream)
+{
+    if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning / test override, read per call
+    const int cols = (int)ldh;                                          // pad columns are produced (as zeros) too
+    // wide outputs only: with few column tiles the register-stationary kernel reads X once as well
+    if (M > 128 || M <= 32 || cols <= 64 || cols > 256 || n_rows < 32768) return SGX_ERR_UNSUPPORTED;
+    if ((uint64_t)P * (uint64_t)ldw * 4ull >= 0xFFF00000ull || (ldw & 3) || ((uintptr_t)Wt & 15)) return SGX_ERR_UNSUPPORTED;
+    const int kb = (M + 15) / 16 <= 4 ? 4 : 8;
+    const int nt = cols <= 128 ? 8 : 16;
+#define SGX_W32(KB_, NT_) return launch_wlds_f32<KB_, NT_>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, x_aligned, h_aligned, ep, relu, stream)
+    if (kb == 4) { if (nt == 8) SGX_W32(4, 8); SGX_W32(4, 16); }
+    if (nt == 8) SGX_W32(8, 8);
+    SGX_W32(8, 16);
+#undef SGX_W32
 }

@@ -744,3 +744,34 @@ def test_xw_dense_fp32_weights_in_registers(M, P):
     assert torch.equal(act, torch.where(got > 0, got, torch.zeros_like(got)))
     base = got._base if got._base is not None else got
     assert not base[:, P:].any()
+
+
+@pytest.mark.parametrize("M,P", [(128, 256), (100, 250), (48, 128), (128, 65), (64, 256), (33, 129)])
+def test_xw_dense_fp32_weights_in_lds(M, P):
+    """fp32 X.W, K <= 128, more than 64 output columns, 32 K rows and more: all of W^T in LDS and every wavefront on all
+    column tiles of its row tiles (xw_dense_wlds_f32_kernel) against the tile kernel -- the same sums in the same order,
+    the same bits -- against torch, with the ReLU on the stores, rows of NaN staying in their rows."""
+    import os
+    from sgracex1_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 17 + P)
+    n = 40_000 + 5
+    X = torch.rand((n, M), generator=g, device="cuda") - 0.4
+    Wt = (torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5
+    bad = torch.tensor([0, 15, 16, 31_999, n - 1], device="cuda")
+    X[bad] = float("nan")
+    got = ops.xw_dense(X, Wt)
+    act = ops.xw_dense(X, Wt, relu=True)
+    os.environ["SGX_XW_NO_WLDS"] = "1"
+    os.environ["SGX_XW_NO_STATIONARY_F32"] = "1"
+    try:
+        tile = ops.xw_dense(X, Wt)
+    finally:
+        del os.environ["SGX_XW_NO_WLDS"], os.environ["SGX_XW_NO_STATIONARY_F32"]
+    ok = torch.ones(n, dtype=torch.bool, device="cuda")
+    ok[bad] = False
+    assert torch.equal(got[ok], tile[ok]) and torch.isnan(got[~ok]).all()
+    torch.testing.assert_close(got[ok], X[ok] @ Wt.t(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(act[ok], torch.where(got[ok] > 0, got[ok], torch.zeros_like(got[ok])))
+    base = got._base if got._base is not None else got
+    assert not base[ok][:, P:].any()
