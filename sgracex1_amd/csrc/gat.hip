@@ -900,7 +900,10 @@ __device__ __forceinline__ void store8(float *__restrict__ dst, int64_t idx, int
 // the maximum and the sum folded across lanes separately (a max / an add per shuffle instead of a softmax merge).
 constexpr int kAloneEdges = 32;
 
-template <typename T, int LH>
+// PART: 0 = everything in one launch; 1 = only the rows of up to kAloneEdges edges (the register pass: a launch of its own
+// needs far fewer registers than the two forms together -- more wavefronts in flight for a kernel that is all latency);
+// 2 = only the longer rows (the cooperative passes).
+template <typename T, int LH, int PART>
 __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
     int n_rows, int n_heads, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const T *__restrict__ val,
     unsigned nnz_bytes_col, const float *__restrict__ s1, const float *__restrict__ s2, unsigned s_bytes, float alpha,
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) nm = max(nm, __shfl_xor(nm, off));
     nm = __builtin_amdgcn_readfirstlane(nm);
-    if (nm > 0) {
+    if (PART != 2 && nm > 0) {
         const float si = (alone && head_ok) ? s1[r * n_heads + h] : 0.0f;
         float x[KB];
         unsigned pos = 0u;
@@ -991,9 +994,10 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
             }
         }
         if (alone && h == 0) dead[r] = l > 0.0f ? 0 : 1;
-    } else if (alone && h == 0) {
+    } else if (PART != 2 && alone && h == 0) {
         dead[r] = 1;             // a wavefront whose rows are all empty: they are rows without a live edge all the same
     }
+    if (PART == 1) return;
 
     // the longer rows of this wavefront, one at a time with every lane: a lane per edge, the heads (8 at a time) in its
     // registers; maximum first, then the sum of exp(x - max), then the weights
@@ -1439,8 +1443,11 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
         const dim3 grid((unsigned)((a.n_rows + rpb - 1) / rpb));
 #define SGX_GAT_LH(L)                                                                                                     \
     case L:                                                                                                               \
-        hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads, a.rowptr, \
-                           a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                          \
+        hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L, 1>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads,      \
+                           a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                \
+                           (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                        \
+        hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L, 2>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads,      \
+                           a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                \
                            (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                        \
         break;
         switch (lh) {
