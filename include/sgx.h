@@ -72,7 +72,8 @@ typedef struct sgx_plan sgx_plan;
 
 /* Builds the plan for rowPtr (device), on the device (csrc/plan_build.hip): the host reads back the entry count and
  * then the number of long rows / tasks it has to size arrays for -- 28 bytes, never rowPtr -- so `stream` is
- * synchronised (three times: twice for those, once before the builder's scratch is freed); not capturable.
+ * synchronised twice (the fill kernels are still in flight on `stream` when this returns; the builder's scratch comes
+ * from the stream-ordered pool); not capturable.
  * n_feat_hint is unused (kept for callers of the first version). */
 int sgx_plan_create(sgx_plan **plan, const int32_t *rowPtr, int n_rows, int n_feat_hint,
                     void *stream);

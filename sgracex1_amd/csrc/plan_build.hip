@@ -266,9 +266,13 @@ __global__ __launch_bounds__(kThreads) void plan_scatter_kernel(const int32_t *_
     }
 }
 
-struct Scratch {                 // freed on every way out of the builder
+// The builder's own scratch comes from the stream-ordered pool and goes back to it on the same stream (on every way
+// out): no synchronisation is needed to free it after the kernels that read it, and a builder called per mini-batch
+// does not pay hipMalloc / hipFree each time.
+struct Scratch {
     void *p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
+    hipStream_t s = nullptr;
+    ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
 };
 
 }  // namespace
@@ -329,8 +333,9 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     } guard{p};
 
     Scratch counts_mem;
+    counts_mem.s = s;
     const size_t counts_bytes = sizeof(PlanCounts) + sizeof(int32_t) * 2 * (size_t)n_blocks;
-    SGX_HIP_CHECK(hipMalloc(&counts_mem.p, counts_bytes));
+    SGX_HIP_CHECK(hipMallocAsync(&counts_mem.p, counts_bytes, s));
     PlanCounts *totals = (PlanCounts *)counts_mem.p;
     int32_t *block_long = (int32_t *)(totals + 1), *block_tasks = block_long + n_blocks;
     SGX_HIP_CHECK(hipMemsetAsync(totals, 0, sizeof(PlanCounts), s));
@@ -370,9 +375,10 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     float reorder_below = kReorderBelow;
     if (const char *f = getenv("SGX_PLAN_REORDER_BELOW")) reorder_below = (float)atof(f);      // tuning override
     Scratch order_mem;
+    order_mem.s = s;
     if (p->natural_utilization < reorder_below && n_rows - p->n_long > 0) {
         const size_t n_counts = (size_t)n_buckets * (size_t)n_blocks;
-        SGX_HIP_CHECK(hipMalloc(&order_mem.p, sizeof(int32_t) * (n_counts + (size_t)n_buckets)));
+        SGX_HIP_CHECK(hipMallocAsync(&order_mem.p, sizeof(int32_t) * (n_counts + (size_t)n_buckets), s));
         int32_t *counts = (int32_t *)order_mem.p, *bucket_base = counts + n_counts;
         SGX_HIP_CHECK(hipMalloc(&p->row_order, sizeof(int32_t) * (size_t)(n_rows - p->n_long)));
         p->n_ordered = n_rows - p->n_long;
@@ -389,8 +395,6 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
                            steps_max, counts, bucket_base, p->row_order);
         SGX_LAUNCH_CHECK();
     }
-    // the scratch arrays are freed when this returns: the kernels that read them have to be done
-    SGX_HIP_CHECK(hipStreamSynchronize(s));
     guard.p = nullptr;
     *out = p;
     return SGX_OK;
