@@ -522,6 +522,7 @@ struct GatArgs {
     const sgx_plan *plan;      // long rows -> split path
     float *split;              // scratch of the split path, behind the scores / column means
     int vec_ok, vec_store;
+    int scores_ready;          // s already holds Wh.a1 / Wh.a2 (formed in the epilogue of the X.W kernel that produced Wh)
     hipStream_t stream;
 };
 
@@ -1485,7 +1486,9 @@ int gat_two_stage(const GatArgs &a)
     const int f_head = a.n_feat / a.n_heads;
     float *s1 = a.s, *s2 = a.s + (size_t)a.n_cols * a.n_heads;
     const int lanes_per_head = VEC > 1 ? f_head / VEC : 0;
-    if (VEC > 1 && a.vec_ok && a.n_feat <= LPR * VEC && f_head % VEC == 0 && lanes_per_head >= 1 && lanes_per_head <= LPR &&
+    if (a.scores_ready) {
+        // (nothing to launch)
+    } else if (VEC > 1 && a.vec_ok && a.n_feat <= LPR * VEC && f_head % VEC == 0 && lanes_per_head >= 1 && lanes_per_head <= LPR &&
         (lanes_per_head & (lanes_per_head - 1)) == 0 &&
         (unsigned long long)a.n_cols * (unsigned long long)a.ldh * sizeof(T) < 0xFFF00000ull) {       // (32-bit buffer offsets)
         int64_t blocks = ((int64_t)a.n_cols + rows_per_block - 1) / rows_per_block;
@@ -1592,6 +1595,15 @@ size_t two_stage_floats(const sgx_plan *plan, int n_heads)
 }
 }  // namespace
 
+// Whether a layer may have its X.W kernel form the attention scores in its epilogue (xw_dense.hip) and hand them to
+// sgx_gat_aggregate_ep as scores_ready: the two-stage form must be the one that runs, and a head must be the 32 columns a
+// lane quad of the MFMA tile holds.
+bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan)
+{
+    return dtype == SGX_F16 && n_heads > 1 && n_feat % n_heads == 0 && n_feat / n_heads == 32 && n_feat % 64 == 0 &&
+           two_stage_ok(plan, n_heads) && !getenv("SGX_GAT_NO_FUSED_SCORES");
+}
+
 extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan)
 {
     if (n_cols < 0 || n_feat < 1) return 0;
@@ -1654,7 +1666,7 @@ extern "C" int sgx_col_sums(int dtype, int n_rows, int n_feat, const void *X, in
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
                          const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
                          const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
-                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill, int ext_n)
+                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill, int ext_n, int scores_ready)
 {
     if (n_heads < 1) n_heads = 1;
     if (plan && plan->n_rows != n_rows) return SGX_ERR_SHAPE;
@@ -1672,6 +1684,8 @@ int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, in
     a.rowptr = rowPtr; a.col = columnIndex; a.val = values; a.Wh = Wh; a.att = attention;
     a.ldh = ldh; a.ldd = ldd; a.h_bytes = (unsigned)table_bytes; a.ld_bytes = (unsigned)(ldh * es);
     a.D = D; a.E = E; a.S = S; a.s = s_scratch; a.stream = stream; a.out_scale = out_scale;
+    a.scores_ready = scores_ready && two_stage_ok(plan, n_heads);      // (only the two-stage form takes them; see sgx_gat_scores_fusable)
+    if (scores_ready && !a.scores_ready) return SGX_ERR_UNSUPPORTED;
     a.fill = ext_fill;                       // a caller-provided row for dead rows (partitioned graph), or the means below
     a.uniform_n = ext_fill ? ext_n : n_cols;
     a.plan = uses_split(plan) ? plan : nullptr;

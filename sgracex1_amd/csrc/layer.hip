@@ -221,7 +221,19 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     }
 
     // stage 1: H = X . W          (loop_fea, K.cpp:2932)
-    if (c.ldc) {
+    int scores_ready = 0;
+    if (d->gat_mode && !q && d->gemm_mode == 1 && d->acc_mode == SGX_ACC_F32 && attention &&
+        sgx_gat_scores_fusable(d->dtype, d->P_w, d->gat_heads, d->plan_adj)) {
+        // heads of 32 columns: the product's epilogue forms the attention scores beside H (one pass over H less)
+        float *s1 = (float *)(ws + c.g_off), *s2 = s1 + (size_t)d->M_adj * d->gat_heads;
+        rc = sgx_xw_dense_scores(d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea, H, ldh, attention, d->gat_heads, s1,
+                                 s2, s);
+        if (rc == SGX_OK) scores_ready = 1;
+        else if (rc != SGX_ERR_UNSUPPORTED) return rc;
+    }
+    if (scores_ready) {
+        rc = SGX_OK;
+    } else if (c.ldc) {
         rc = sgx_xw_dense_i8(q->qbits, d->M_adj, d->M_fea, d->P_w, (const int8_t *)values_fea, c.ldc, (const int8_t *)B, c.ldc,
                              q->scale_fea, q->internal_bits, (float *)H, ldh, ws + c.q_off + c.qw, s);
     } else if (d->gemm_mode == 0) {
@@ -248,7 +260,7 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
         rc = sgx_gat_aggregate_ep(d->dtype, d->relu, d->gat_fill_dead_rows, d->N_adj, d->M_adj, d->P_w, d->gat_heads, d->alpha,
                                   d->rowPtr_adj, d->columnIndex_adj,
                                   values_adj, H, ldh, attention, d->D, d->P_w, (float *)d->E, (float *)d->S, d->plan_adj,
-                                  (float *)(ws + c.g_off), s, ep_d.out_scale);
+                                  (float *)(ws + c.g_off), s, ep_d.out_scale, nullptr, 0, scores_ready);
     } else {
         rc = sgx_spmm_launch(d->dtype, d->acc_mode, d->spmm_block, d->relu, d->N_adj, d->M_adj, d->P_w,
                              d->rowPtr_adj, d->columnIndex_adj, values_adj, H, ldh, d->D, d->P_w, d->plan_adj,

@@ -120,4 +120,11 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,
                          const int32_t *rowPtr, const int32_t *columnIndex, const void *values, const void *Wh, int64_t ldh,
                          const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
-                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill = nullptr, int ext_n = 0);
+                         float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill = nullptr, int ext_n = 0,
+                         int scores_ready = 0);
+// GAT layer: the attention scores formed by the X.W kernel's epilogue (fp16, heads of 32 columns, two-stage aggregate)
+bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan);
+// sgx_xw_dense_ep for that case: s1 / s2 [n_rows x n_heads] = H.a1 / H.a2 per head beside H; SGX_ERR_UNSUPPORTED when
+// the shape is not the stationary kernel's (the caller then runs the plain product and lets the aggregate form the scores)
+int sgx_xw_dense_scores(int n_rows, int M_fea, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                        const void *attention, int n_heads, float *s1, float *s2, hipStream_t stream);

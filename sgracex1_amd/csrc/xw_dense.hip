@@ -212,11 +212,17 @@ __global__ __launch_bounds__(kBlock) void xw_dense_f32_kernel(
 // G = ceil(P/16 / NTW) column groups; consecutive wavefronts (one workgroup) take the G groups of
 // the same row tile, so the G-fold re-read of X hits L1/L2.
 // ---------------------------------------------------------------------------------------
-template <int KS, int NTW, int MT>
+// SC (GAT layer, heads of 32 columns, NTW even): beside H the kernel forms the attention scores s1 = H.a1, s2 = H.a2 per
+// (row, head) from the ROUNDED values it stores -- a pair of tiles hands a lane quad the 32 columns of one head, 8 per
+// lane: the same eight-term fma chain per lane and the same two-step tree over the four lanes as gat_scores_rows_kernel
+// (gat.hip), hence the same bits -- which saves that kernel's pass over H (87 MB on the ogbn-arxiv shape: 35 us).
+template <int KS, int NTW, int MT, int SC = 0>
 __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     int n_rows, int M, int P, int col_groups, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt,
-    int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu)
+    int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu, const f16 *__restrict__ att = nullptr,
+    float *__restrict__ s1 = nullptr, float *__restrict__ s2 = nullptr, int n_heads = 0)
 {
+    static_assert(!SC || NTW % 2 == 0, "a head is the 32 columns of a pair of tiles");
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -242,6 +248,19 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
             const int n = column_of(nt, l15);
             a[ks][nt] = load_k8(Wt + (int64_t)n * ldw, ks * 32 + 8 * lq, M, n < P, true);
         }
+    // SC: this lane's 8 columns of each of its heads (pair q of tiles = head n_base / 32 + q): the attention fragments
+    float att1[SC ? NTW / 2 : 1][8], att2[SC ? NTW / 2 : 1][8];
+    if constexpr (SC != 0) {
+#pragma unroll
+        for (int q = 0; q < NTW / 2; ++q) {
+            const int head = n_base / 32 + q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                att1[q][j] = head < n_heads ? (float)att[(int64_t)head * 64 + 8 * lq + j] : 0.0f;
+                att2[q][j] = head < n_heads ? (float)att[(int64_t)head * 64 + 32 + 8 * lq + j] : 0.0f;
+            }
+        }
+    }
 
     const int64_t n_tiles = (n_rows + MT * 16 - 1) / (MT * 16);
     f16x8 b[KS][MT], b_next[KS][MT];
@@ -285,6 +304,28 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t m = tile * (MT * 16) + mt * 16 + l15;
+            if constexpr (SC != 0) {
+                // (before the row check: the tree runs over all four lanes of a row)
+#pragma unroll
+                for (int q = 0; q < NTW / 2; ++q) {
+                    float p1 = 0.0f, p2 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = (float)relu_f16((f16)acc[mt][2 * q + j / 4][j % 4], relu);
+                        p1 = __builtin_fmaf(x, att1[q][j], p1);
+                        p2 = __builtin_fmaf(x, att2[q][j], p2);
+                    }
+                    p1 += __shfl_xor(p1, 16);
+                    p2 += __shfl_xor(p2, 16);
+                    p1 += __shfl_xor(p1, 32);
+                    p2 += __shfl_xor(p2, 32);
+                    const int head = n_base / 32 + q;
+                    if (lq == 0 && m < n_rows && head < n_heads) {
+                        s1[m * n_heads + head] = p1;
+                        s2[m * n_heads + head] = p2;
+                    }
+                }
+            }
             if (m >= n_rows) continue;
             if constexpr (PAIRED) {
 #pragma unroll
@@ -571,6 +612,24 @@ int try_stationary_f32(int n_rows, int M, int P, const void *X, int64_t ldx, con
 #undef SGX_ST32
 }
 
+template <int KS>
+int launch_stationary_scores(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                             int ha, const void *att, int n_heads, float *s1, float *s2, hipStream_t s)
+{
+    constexpr int NTW = 4, MT = 2;
+    const int nt_total = (int)((ldh + 15) / 16);
+    const int groups = (nt_total + NTW - 1) / NTW;
+    const int64_t n_tiles = ((int64_t)n_rows + MT * 16 - 1) / (MT * 16);
+    int64_t waves = (int64_t)256 * 8 * (kBlock / 64);
+    if (waves > n_tiles * groups) waves = n_tiles * groups;
+    waves = (waves + groups - 1) / groups * groups;
+    const unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL((xw_dense_stationary_f16_kernel<KS, NTW, MT, 1>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
+                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, 0, (const f16 *)att, s1, s2, n_heads);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
+}
+
 template <int NT, int MT>
 int launch_tile(int dtype, int n_rows, int M, int P, int p_base, const void *X, int64_t ldx, const void *Wt,
                 int64_t ldw, void *H, int64_t ldh, int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
@@ -664,4 +723,18 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         if (rc != SGX_OK) return rc;
     }
     return SGX_OK;
+}
+
+// X.W of a GAT layer with the attention scores formed beside H (see the SC form of the stationary kernel): fp16, K <= 128,
+// heads of 32 columns, P a multiple of 64, 8 K rows and more.
+int sgx_xw_dense_scores(int n_rows, int M_fea, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+                        const void *attention, int n_heads, float *s1, float *s2, hipStream_t stream)
+{
+    if (n_rows < 8192 || M_fea < 1 || M_fea > 128 || P < 64 || P % 64 != 0 || n_heads * 32 != P || ldh < P || ldx < M_fea || ldw < M_fea)
+        return SGX_ERR_UNSUPPORTED;
+    if (!X || !Wt || !H || !attention || !s1 || !s2) return SGX_ERR_NULL;
+    const int ha = ((uintptr_t)H % 8 == 0) && ((ldh * 2) % 8 == 0);
+    const int ks = (M_fea + 31) / 32;
+    if (ks <= 2) return launch_stationary_scores<2>(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, attention, n_heads, s1, s2, stream);
+    return launch_stationary_scores<4>(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, attention, n_heads, s1, s2, stream);
 }

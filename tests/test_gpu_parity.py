@@ -775,3 +775,32 @@ def test_xw_dense_fp32_weights_in_lds(M, P):
     assert torch.equal(act[ok], torch.where(got[ok] > 0, got[ok], torch.zeros_like(got[ok])))
     base = got._base if got._base is not None else got
     assert not base[ok][:, P:].any()
+
+
+@pytest.mark.parametrize("M,P,heads", [(128, 256, 8), (100, 256, 8), (64, 128, 4), (40, 64, 2)])
+@pytest.mark.parametrize("gen_name", ["uniform", "rmat"])
+def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
+    """A GAT layer with heads of 32 columns: the X.W kernel forms the attention scores beside H (SC form of the stationary
+    kernel) instead of a pass over H of its own.  Same eight-term chains and the same tree as the scores kernel, so the layer
+    equals -- bit for bit -- the same layer with SGX_GAT_NO_FUSED_SCORES and the composition xw_dense + gat_aggregate;
+    E and S too."""
+    import os
+    from sgracex1_amd import graphs, ops
+    n = 24_000 + 7
+    A = (graphs.rmat_graph_n if gen_name == "rmat" else graphs.uniform_graph)(n, 400_000, seed=M + P)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M * 3 + P)
+    X = (torch.rand((n, M), generator=g, device="cuda") - 0.4).half()
+    Wt = ((torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5).half()
+    att = ((torch.rand(heads * 64, generator=g, device="cuda") * 2 - 1) * 0.3).half()
+    fused, E, S = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
+    os.environ["SGX_GAT_NO_FUSED_SCORES"] = "1"
+    try:
+        plain, E0, S0 = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
+    finally:
+        del os.environ["SGX_GAT_NO_FUSED_SCORES"]
+    assert torch.equal(fused, plain) and torch.equal(E, E0) and torch.equal(S, S0)
+    Wh = ops.xw_dense(X, Wt)
+    composed = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
+    assert torch.equal(fused, composed)
+    assert torch.isfinite(fused.float()).all()
