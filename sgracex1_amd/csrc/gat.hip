@@ -1569,10 +1569,18 @@ int gat_launch_lpr(const GatArgs &a, int lpr)
 }  // namespace
 
 namespace {
+// heads of a whole number of 64-column groups: the X.W kernel of a layer may leave the scores as one partial per
+// (row, group) for gat_scores_combine_kernel to add up (sgx_gat_score_partials)
+bool score_partials_possible(int n_feat, int n_heads) { return n_heads >= 1 && n_feat % n_heads == 0 && (n_feat / n_heads) % 64 == 0; }
+size_t score_partial_floats(int n_cols, int n_feat, int n_heads)
+{
+    return score_partials_possible(n_feat, n_heads) ? (size_t)2 * n_cols * (n_feat / 64) : 0;
+}
 size_t base_scratch_floats(int n_cols, int n_feat, int n_heads, int fill_dead_rows)
 {
     size_t floats = (size_t)2 * n_cols * n_heads;
     if (fill_dead_rows) floats += (size_t)(kMeanSlabs + 1) * n_feat;
+    floats += score_partial_floats(n_cols, n_feat, n_heads);
     return sgx_align_up(floats, 64);
 }
 bool uses_split(const sgx_plan *plan) { return plan && plan->n_long > 0; }
@@ -1600,8 +1608,53 @@ size_t two_stage_floats(const sgx_plan *plan, int n_heads)
 // lane quad of the MFMA tile holds.
 bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan)
 {
-    return dtype == SGX_F16 && n_heads > 1 && n_feat % n_heads == 0 && n_feat / n_heads == 32 && n_feat % 64 == 0 &&
-           two_stage_ok(plan, n_heads) && !getenv("SGX_GAT_NO_FUSED_SCORES");
+    if (n_heads < 1) n_heads = 1;
+    if (dtype != SGX_F16 || n_feat % n_heads != 0 || n_feat % 64 != 0 || !two_stage_ok(plan, n_heads) || getenv("SGX_GAT_NO_FUSED_SCORES"))
+        return false;
+    const int f_head = n_feat / n_heads;
+    return f_head == 32 || f_head % 64 == 0;         // a head = a lane quad's pair of tiles, or whole 64-column groups of a wavefront
+}
+
+// where the per-group partial scores of that form go: behind the scores and the column means of the scratch
+float *sgx_gat_score_partials(float *s_scratch, int n_cols, int n_feat, int n_heads, int fill_dead_rows)
+{
+    if (n_heads < 1) n_heads = 1;
+    if (!score_partials_possible(n_feat, n_heads)) return nullptr;
+    return s_scratch + (size_t)2 * n_cols * n_heads + (fill_dead_rows ? (size_t)(kMeanSlabs + 1) * n_feat : 0);
+}
+
+namespace {
+// s[r][h] = the groups of head h added in the order of the scores kernel's lane tree: (g0 + g1) + (g2 + g3) ...
+__global__ __launch_bounds__(kBlock) void gat_scores_combine_kernel(int64_t n_pairs, int n_heads, int groups_per_head, int n_groups,
+                                                                    const float *__restrict__ sp1, const float *__restrict__ sp2,
+                                                                    float *__restrict__ s1, float *__restrict__ s2)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int64_t r = i / n_heads;
+    const int h = (int)(i % n_heads);
+    const float *p1 = sp1 + r * n_groups + (int64_t)h * groups_per_head, *p2 = sp2 + r * n_groups + (int64_t)h * groups_per_head;
+    float a1[8], a2[8];                              // (up to 512 columns per head)
+    for (int g = 0; g < groups_per_head; ++g) { a1[g] = p1[g]; a2[g] = p2[g]; }
+    for (int width = 1; width < groups_per_head; width <<= 1)
+        for (int g = 0; g + width < groups_per_head; g += 2 * width) { a1[g] += a1[g + width]; a2[g] += a2[g + width]; }
+    s1[i] = a1[0];
+    s2[i] = a2[0];
+}
+}  // namespace
+
+// the partial scores of sgx_xw_dense_scores (heads of 64 columns and more) added up into s_scratch's s1 / s2
+int sgx_gat_scores_combine(float *s_scratch, int n_cols, int n_feat, int n_heads, int fill_dead_rows, hipStream_t stream)
+{
+    if (n_heads < 1) n_heads = 1;
+    float *sp1 = sgx_gat_score_partials(s_scratch, n_cols, n_feat, n_heads, fill_dead_rows);
+    const int n_groups = n_feat / 64, gph = n_groups / n_heads;
+    if (!sp1 || gph < 1 || gph > 8 || (gph & (gph - 1))) return SGX_ERR_UNSUPPORTED;
+    const int64_t pairs = (int64_t)n_cols * n_heads;
+    hipLaunchKernelGGL(gat_scores_combine_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, pairs, n_heads,
+                       gph, n_groups, sp1, sp1 + (size_t)n_cols * n_groups, s_scratch, s_scratch + (size_t)n_cols * n_heads);
+    SGX_LAUNCH_CHECK();
+    return SGX_OK;
 }
 
 extern "C" size_t sgx_gat_scratch_bytes(int n_cols, int n_feat, int n_heads, int fill_dead_rows, const sgx_plan *plan)

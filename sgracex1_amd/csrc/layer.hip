@@ -224,10 +224,16 @@ extern "C" int sgx_layer_forward(const sgx_layer_desc *d, void *stream)
     int scores_ready = 0;
     if (d->gat_mode && !q && d->gemm_mode == 1 && d->acc_mode == SGX_ACC_F32 && attention &&
         sgx_gat_scores_fusable(d->dtype, d->P_w, d->gat_heads, d->plan_adj)) {
-        // heads of 32 columns: the product's epilogue forms the attention scores beside H (one pass over H less)
-        float *s1 = (float *)(ws + c.g_off), *s2 = s1 + (size_t)d->M_adj * d->gat_heads;
-        rc = sgx_xw_dense_scores(d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea, H, ldh, attention, d->gat_heads, s1,
-                                 s2, s);
+        // the product's epilogue forms the attention scores beside H (one pass over H less)
+        // heads of 32 columns: the scores themselves; wider heads: a partial per 64-column group, added up by a small kernel
+        const int heads = d->gat_heads < 1 ? 1 : d->gat_heads;
+        float *gs = (float *)(ws + c.g_off);
+        const bool direct = d->P_w / heads == 32;
+        float *s1 = direct ? gs : sgx_gat_score_partials(gs, d->M_adj, d->P_w, heads, d->gat_fill_dead_rows);
+        float *s2 = s1 ? s1 + (size_t)d->M_adj * (direct ? heads : d->P_w / 64) : nullptr;
+        rc = s1 ? sgx_xw_dense_scores(d->M_adj, d->M_fea, d->P_w, values_fea, d->M_fea, B, d->M_fea, H, ldh, attention, heads, s1, s2, s)
+                : SGX_ERR_UNSUPPORTED;
+        if (rc == SGX_OK && !direct) rc = sgx_gat_scores_combine(gs, d->M_adj, d->P_w, heads, d->gat_fill_dead_rows, s);
         if (rc == SGX_OK) scores_ready = 1;
         else if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }

@@ -124,7 +124,11 @@ int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, in
                          int scores_ready = 0);
 // GAT layer: the attention scores formed by the X.W kernel's epilogue (fp16, heads of 32 columns, two-stage aggregate)
 bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan);
+float *sgx_gat_score_partials(float *s_scratch, int n_cols, int n_feat, int n_heads, int fill_dead_rows);
+int sgx_gat_scores_combine(float *s_scratch, int n_cols, int n_feat, int n_heads, int fill_dead_rows, hipStream_t stream);
 // sgx_xw_dense_ep for that case: s1 / s2 [n_rows x n_heads] = H.a1 / H.a2 per head beside H; SGX_ERR_UNSUPPORTED when
 // the shape is not the stationary kernel's (the caller then runs the plain product and lets the aggregate form the scores)
+// (heads of 32 columns: s1 / s2 are the scores themselves; heads of 64 columns and more: one partial per (row, 64-column
+// group), [n_rows x P / 64] each, for sgx_gat_scores_combine)
 int sgx_xw_dense_scores(int n_rows, int M_fea, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                         const void *attention, int n_heads, float *s1, float *s2, hipStream_t stream);

@@ -220,9 +220,12 @@ template <int KS, int NTW, int MT, int SC = 0>
 __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     int n_rows, int M, int P, int col_groups, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt,
     int64_t ldw, f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu, const f16 *__restrict__ att = nullptr,
-    float *__restrict__ s1 = nullptr, float *__restrict__ s2 = nullptr, int n_heads = 0)
+    float *__restrict__ s1 = nullptr, float *__restrict__ s2 = nullptr, int n_heads = 0, int f_head = 32)
 {
-    static_assert(!SC || NTW % 2 == 0, "a head is the 32 columns of a pair of tiles");
+    // SC == 2: heads of whole 64-column groups -- the wavefront's 64 columns give one PARTIAL per row (its two quads' sums
+    // added: the next level of the same tree), s1 / s2 are [n_rows x P / 64] and gat_scores_combine_kernel adds the groups
+    // of a head in the tree's order.
+    static_assert(!SC || NTW == 4, "a wavefront's columns = one 64-column group = two pairs of tiles");
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, lq = lane >> 4;
     const int64_t gw = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -253,11 +256,12 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
     if constexpr (SC != 0) {
 #pragma unroll
         for (int q = 0; q < NTW / 2; ++q) {
-            const int head = n_base / 32 + q;
+            const int c0 = n_base + 32 * q + 8 * lq;                 // this lane's first column of the pair
+            const int head = c0 / f_head, j0 = c0 - head * f_head;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                att1[q][j] = head < n_heads ? (float)att[(int64_t)head * 64 + 8 * lq + j] : 0.0f;
-                att2[q][j] = head < n_heads ? (float)att[(int64_t)head * 64 + 32 + 8 * lq + j] : 0.0f;
+                att1[q][j] = head < n_heads ? (float)att[(int64_t)head * 2 * f_head + j0 + j] : 0.0f;
+                att2[q][j] = head < n_heads ? (float)att[(int64_t)head * 2 * f_head + f_head + j0 + j] : 0.0f;
             }
         }
     }
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
             const int64_t m = tile * (MT * 16) + mt * 16 + l15;
             if constexpr (SC != 0) {
                 // (before the row check: the tree runs over all four lanes of a row)
+                float g1 = 0.0f, g2 = 0.0f;
 #pragma unroll
                 for (int q = 0; q < NTW / 2; ++q) {
                     float p1 = 0.0f, p2 = 0.0f;
@@ -319,10 +324,22 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
                     p2 += __shfl_xor(p2, 16);
                     p1 += __shfl_xor(p1, 32);
                     p2 += __shfl_xor(p2, 32);
-                    const int head = n_base / 32 + q;
-                    if (lq == 0 && m < n_rows && head < n_heads) {
-                        s1[m * n_heads + head] = p1;
-                        s2[m * n_heads + head] = p2;
+                    if constexpr (SC == 1) {
+                        const int head = n_base / 32 + q;
+                        if (lq == 0 && m < n_rows && head < n_heads) {
+                            s1[m * n_heads + head] = p1;
+                            s2[m * n_heads + head] = p2;
+                        }
+                    } else {
+                        g1 = q == 0 ? p1 : g1 + p1;
+                        g2 = q == 0 ? p2 : g2 + p2;
+                    }
+                }
+                if constexpr (SC == 2) {
+                    const int n_groups = P / 64;
+                    if (lq == 0 && m < n_rows && cg < n_groups) {
+                        s1[m * n_groups + cg] = g1;
+                        s2[m * n_groups + cg] = g2;
                     }
                 }
             }
@@ -612,7 +629,7 @@ int try_stationary_f32(int n_rows, int M, int P, const void *X, int64_t ldx, con
 #undef SGX_ST32
 }
 
-template <int KS>
+template <int KS, int SC>
 int launch_stationary_scores(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                              int ha, const void *att, int n_heads, float *s1, float *s2, hipStream_t s)
 {
@@ -624,8 +641,8 @@ int launch_stationary_scores(int n_rows, int M, int P, const void *X, int64_t ld
     if (waves > n_tiles * groups) waves = n_tiles * groups;
     waves = (waves + groups - 1) / groups * groups;
     const unsigned grid = (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
-    hipLaunchKernelGGL((xw_dense_stationary_f16_kernel<KS, NTW, MT, 1>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
-                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, 0, (const f16 *)att, s1, s2, n_heads);
+    hipLaunchKernelGGL((xw_dense_stationary_f16_kernel<KS, NTW, MT, SC>), dim3(grid), dim3(kBlock), 0, s, n_rows, M, P, groups,
+                       (const f16 *)X, ldx, (const f16 *)Wt, ldw, (f16 *)H, ldh, ha, 0, (const f16 *)att, s1, s2, n_heads, P / n_heads);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -730,11 +747,17 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
 int sgx_xw_dense_scores(int n_rows, int M_fea, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                         const void *attention, int n_heads, float *s1, float *s2, hipStream_t stream)
 {
-    if (n_rows < 8192 || M_fea < 1 || M_fea > 128 || P < 64 || P % 64 != 0 || n_heads * 32 != P || ldh < P || ldx < M_fea || ldw < M_fea)
+    if (n_heads < 1) n_heads = 1;
+    if (n_rows < 8192 || M_fea < 1 || M_fea > 128 || P < 64 || P % 64 != 0 || P % n_heads != 0 || ldh < P || ldx < M_fea || ldw < M_fea)
         return SGX_ERR_UNSUPPORTED;
+    const int f_head = P / n_heads;
+    if (f_head != 32 && f_head % 64 != 0) return SGX_ERR_UNSUPPORTED;
     if (!X || !Wt || !H || !attention || !s1 || !s2) return SGX_ERR_NULL;
     const int ha = ((uintptr_t)H % 8 == 0) && ((ldh * 2) % 8 == 0);
     const int ks = (M_fea + 31) / 32;
-    if (ks <= 2) return launch_stationary_scores<2>(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, attention, n_heads, s1, s2, stream);
-    return launch_stationary_scores<4>(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, attention, n_heads, s1, s2, stream);
+#define SGX_SC(KS_, SC_) return launch_stationary_scores<KS_, SC_>(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, attention, n_heads, s1, s2, stream)
+    if (f_head == 32) { if (ks <= 2) SGX_SC(2, 1); SGX_SC(4, 1); }
+    if (ks <= 2) SGX_SC(2, 2);
+    SGX_SC(4, 2);
+#undef SGX_SC
 }

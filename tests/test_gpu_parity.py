@@ -777,13 +777,15 @@ def test_xw_dense_fp32_weights_in_lds(M, P):
     assert not base[ok][:, P:].any()
 
 
-@pytest.mark.parametrize("M,P,heads", [(128, 256, 8), (100, 256, 8), (64, 128, 4), (40, 64, 2)])
+@pytest.mark.parametrize("M,P,heads", [(128, 256, 8), (100, 256, 8), (64, 128, 4), (40, 64, 2), (128, 256, 1), (100, 256, 2),
+                                       (64, 128, 1), (33, 64, 1), (128, 512, 1)])
 @pytest.mark.parametrize("gen_name", ["uniform", "rmat"])
 def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
-    """A GAT layer with heads of 32 columns: the X.W kernel forms the attention scores beside H (SC form of the stationary
-    kernel) instead of a pass over H of its own.  Same eight-term chains and the same tree as the scores kernel, so the layer
-    equals -- bit for bit -- the same layer with SGX_GAT_NO_FUSED_SCORES and the composition xw_dense + gat_aggregate;
-    E and S too."""
+    """A GAT layer whose heads are 32 columns or whole 64-column groups (one head of 256: the reference's semantics; 8 of
+    32: BASELINE's configuration 5): the X.W kernel forms the attention scores beside H (SC forms of the stationary kernel;
+    wide heads as a partial per 64-column group, added by a small kernel in the scores kernel's tree order) instead of a
+    pass over H of its own.  Same eight-term chains and the same tree, so the layer equals -- bit for bit -- the same layer
+    with SGX_GAT_NO_FUSED_SCORES and the composition xw_dense + gat_aggregate; E and S too."""
     import os
     from sgracex1_amd import graphs, ops
     n = 24_000 + 7
@@ -792,7 +794,7 @@ def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
     g.manual_seed(M * 3 + P)
     X = (torch.rand((n, M), generator=g, device="cuda") - 0.4).half()
     Wt = ((torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5).half()
-    att = ((torch.rand(heads * 64, generator=g, device="cuda") * 2 - 1) * 0.3).half()
+    att = ((torch.rand(2 * P, generator=g, device="cuda") * 2 - 1) * 0.3).half()
     fused, E, S = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
     os.environ["SGX_GAT_NO_FUSED_SCORES"] = "1"
     try:
