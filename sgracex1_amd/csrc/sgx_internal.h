@@ -111,10 +111,10 @@ int sgx_repitch_rows(const void *src, int64_t src_pitch, void *dst, int64_t dst_
                      hipStream_t stream);
 // X.W, fp16, long K, the weight tile resident in LDS (xw_dense_wlds.hip); SGX_ERR_UNSUPPORTED = not its shape
 int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
-                      int h_aligned, int relu, hipStream_t stream);
+                      int relu, hipStream_t stream);
 // the fp32 counterpart for K <= 128 and wide outputs (W^T for all columns in LDS, X read once)
 int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
-                          int x_aligned, int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream);
+                          int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream);
 int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_fea, int P, const void *X, int64_t ldx,
                     const void *Wt, int64_t ldw, void *H, int64_t ldh, hipStream_t stream, sgx_epilogue ep, int relu = 0);
 int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, int n_cols, int n_feat, int n_heads, float alpha,

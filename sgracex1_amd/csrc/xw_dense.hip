@@ -705,7 +705,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         const int rc = try_stationary(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, s, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     } else {
-        int rc = sgx_xw_dense_wlds_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, ha, ep, relu, s);
+        int rc = sgx_xw_dense_wlds_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, ep, relu, s);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
         rc = try_stationary_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
@@ -715,7 +715,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
     const bool tall = n_rows >= 32768 && !short_tiles;
     if (dtype == SGX_F16 && tall && !no_lds && M_fea > 128) {
         // all of W^T in LDS, X streamed through a register ring (xw_dense_wlds.hip): 602 -> 128 on 233 K rows
-        const int rc = sgx_xw_dense_wlds(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, ha, relu, s);
+        const int rc = sgx_xw_dense_wlds(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, relu, s);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
         const dim3 grid((unsigned)((n_rows + kLdsBM - 1) / kLdsBM), (unsigned)((ldh + kLdsBN - 1) / kLdsBN));
         hipLaunchKernelGGL(xw_dense_lds_f16_kernel, grid, dim3(kBlock), 0, s, n_rows, M_fea, P, (const f16 *)X, ldx,

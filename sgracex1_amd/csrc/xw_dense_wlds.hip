@@ -5,9 +5,11 @@
 // global loads in flight per workgroup: 3 workgroups x 8 KB of X per CU = 6 MB on the chip, where 8 TB/s x ~2 us of
 // latency wants 16 MB -- Reddit's 602 -> 128 ran at 2.4 TB/s (0.30 of the HBM roofline).  Here a workgroup of 8
 // wavefronts copies its column block of W^T (all of K: 128 x 602 halves = 154 KB) into LDS once and then only streams
-// X: every wavefront owns 32-row tiles, loads the MFMA B fragments of X straight from HBM into a ring of kRing k-steps
-// (16 bytes per lane, 2 KB per step and wavefront: 96 KB in flight per CU), reads the A fragments of W from LDS, and
-// never meets a barrier after the fill.  X is read once, H written once.
+// X: every wavefront owns 32-row tiles, loads the MFMA B fragments of X straight from HBM into a ring of kRing PAIRS of
+// k-steps (16 bytes per lane and load, 128 bytes of a row per pair: 16 KB in flight per wavefront, 128 KB per CU), reads
+// the A fragments of W from LDS, and never meets a barrier after the fill.  X is read once, H written once -- its tiles
+// leave as 16-byte pieces spread over the k-steps (see the step lambda) so that the stores never queue up behind the
+// ring's loads.
 //
 // Orientation as in xw_dense.hip: H^T[n][m] = sum_k Wt[n][k] X[m][k], A := rows of W^T (LDS), B := rows of X, so a
 // lane ends with 4 consecutive columns of one row of H; k-steps of 32 in ascending order into v_mfma_f32_16x16x32_f16
@@ -42,7 +44,7 @@ __device__ __forceinline__ f16 relu_half(f16 v, int relu) { return (!relu || v >
 template <int NT>
 __global__ __launch_bounds__(kWldsThreads) void xw_dense_wlds_f16_kernel(
     int n_rows, int M, int P, const f16 *__restrict__ X, int64_t ldx, const f16 *__restrict__ Wt, int64_t ldw,
-    f16 *__restrict__ H, int64_t ldh, int h_aligned, int relu, int n_cb, int LP, int KS)
+    f16 *__restrict__ H, int64_t ldh, int relu, int n_cb, int LP, int KS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     f16 *sW = reinterpret_cast<f16 *>(lds_raw);                 // [16 NT][LP]
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kWldsThreads) void xw_dense_wlds_f16_kernel(
 
 template <int NT>
 int launch_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
-                int ha, int relu, int n_cb, int LP, int KS, hipStream_t s)
+                int relu, int n_cb, int LP, int KS, hipStream_t s)
 {
     auto kernel = xw_dense_wlds_f16_kernel<NT>;
     const size_t lds_bytes = (size_t)16 * NT * LP * 2;
@@ -262,7 +264,7 @@ int launch_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void
     if (want < grid) grid = (int)want;
     if (grid < 8 * n_cb) grid = 8 * n_cb;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kWldsThreads), lds_bytes, s, n_rows, M, P, (const f16 *)X, ldx, (const f16 *)Wt, ldw,
-                       (f16 *)H, ldh, ha, relu, n_cb, LP, KS);
+                       (f16 *)H, ldh, relu, n_cb, LP, KS);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -271,9 +273,9 @@ int launch_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void
 
 // SGX_ERR_UNSUPPORTED: the shape is not this kernel's (the caller goes on to the tile kernels)
 int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
-                      int h_aligned, int relu, hipStream_t stream)
+                      int relu, hipStream_t stream)
 {
-    if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning override, read per call (tools/bench_configs.py flips it)
+    if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning override, read per call (tools/xw_dense_long_k_probe.py flips it)
     if (M <= 128 || n_rows < 32768) return SGX_ERR_UNSUPPORTED;
     // X through 32-bit buffer offsets, 4-byte aligned rows (a 16-byte buffer load wants dword alignment)
     if ((uint64_t)n_rows * (uint64_t)ldx * 2ull >= 0xFFF00000ull || (ldx & 1) || ((uintptr_t)X & 3)) return SGX_ERR_UNSUPPORTED;
@@ -291,9 +293,9 @@ int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, cons
     }                                                                   // ... or the widest that fits, X then read once per block
     if (nt == 0 || n_cb > 2) return SGX_ERR_UNSUPPORTED;
     switch (nt) {
-    case 2: return launch_wlds<2>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, relu, n_cb, LP, KS, stream);
-    case 4: return launch_wlds<4>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, relu, n_cb, LP, KS, stream);
-    default: return launch_wlds<8>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, relu, n_cb, LP, KS, stream);
+    case 2: return launch_wlds<2>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, relu, n_cb, LP, KS, stream);
+    case 4: return launch_wlds<4>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, relu, n_cb, LP, KS, stream);
+    default: return launch_wlds<8>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, relu, n_cb, LP, KS, stream);
     }
 }
 
@@ -312,7 +314,7 @@ constexpr int kW32Threads = 512;
 template <int KB, int NT>
 __global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
     int n_rows, int M, int P, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt, int64_t ldw,
-    float *__restrict__ H, int64_t ldh, int x_aligned, int h_aligned, sgx_epilogue ep, int relu)
+    float *__restrict__ H, int64_t ldh, int h_aligned, sgx_epilogue ep, int relu)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw32[];
     float *sW = reinterpret_cast<float *>(lds_raw32);            // [16 NT][LP]
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
 }
 
 template <int KB, int NT>
-int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh, int xa,
+int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                     int ha, sgx_epilogue ep, int relu, hipStream_t s)
 {
     auto kernel = xw_dense_wlds_f32_kernel<KB, NT>;
@@ -443,7 +445,7 @@ int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const 
     const int64_t want = (tiles + kW32Threads / 64 - 1) / (kW32Threads / 64);
     if (want < grid) grid = want;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kW32Threads), lds_bytes, s, n_rows, M, P, (const float *)X, ldx,
-                       (const float *)Wt, ldw, (float *)H, ldh, xa, ha, ep, relu);
+                       (const float *)Wt, ldw, (float *)H, ldh, ha, ep, relu);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -452,7 +454,7 @@ int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const 
 
 // SGX_ERR_UNSUPPORTED: not this kernel's shape (the caller goes on to the register-stationary and tile kernels)
 int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
-                          int x_aligned, int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream)
+                          int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream)
 {
     if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning / test override, read per call
     const int cols = (int)ldh;                                          // pad columns are produced (as zeros) too
@@ -461,7 +463,7 @@ int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, 
     if ((uint64_t)P * (uint64_t)ldw * 4ull >= 0xFFF00000ull || (ldw & 3) || ((uintptr_t)Wt & 15)) return SGX_ERR_UNSUPPORTED;
     const int kb = (M + 15) / 16 <= 4 ? 4 : 8;
     const int nt = cols <= 128 ? 8 : 16;
-#define SGX_W32(KB_, NT_) return launch_wlds_f32<KB_, NT_>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, x_aligned, h_aligned, ep, relu, stream)
+#define SGX_W32(KB_, NT_) return launch_wlds_f32<KB_, NT_>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, ep, relu, stream)
     if (kb == 4) { if (nt == 8) SGX_W32(4, 8); SGX_W32(4, 16); }
     if (nt == 8) SGX_W32(8, 8);
     SGX_W32(8, 16);
