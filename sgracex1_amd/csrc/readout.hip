@@ -18,6 +18,7 @@ __global__ __launch_bounds__(kBlock) void readout_mean_linear_kernel(
 {
     extern __shared__ float mean[];                       // [F]
     const int g = blockIdx.x;
+    if (g >= n_graphs) return;                            // (the grid is one workgroup per graph)
     const int r0 = ptr[g], r1 = ptr[g + 1];
     const float inv = r1 > r0 ? 1.0f / (float)(r1 - r0) : 0.0f;
     for (int j = threadIdx.x; j < F; j += kBlock) {
