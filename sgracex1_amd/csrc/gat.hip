@@ -913,8 +913,11 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
     constexpr int RPW = 64 / LH;
     constexpr int KB = kAloneEdges;
     const int lane = threadIdx.x & 63, h = lane % LH, grp = lane / LH;
-    const int64_t r_first = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * RPW;
-    const int64_t r = r_first + grp;
+    // PART 2 deals the rows out cyclically (slot g of wavefront w takes row g W + w, W = all wavefronts): the longer rows of
+    // a power-law graph sit next to each other, and taken 8 to a wavefront they would queue up behind one another
+    const int64_t gwave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t r = PART == 2 ? (int64_t)grp * n_waves + gwave : gwave * RPW + grp;
     const bool head_ok = h < n_heads;
     int e0 = 0, e1 = 0;
     if (r < n_rows) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
         const int dg = __shfl(coop_deg, g * LH);
         if (dg == 0) continue;                                                     // wave-uniform
         const int ge0 = __shfl(e0, g * LH), ge1 = ge0 + dg;
-        const int64_t gr = r_first + g;
+        const int64_t gr = PART == 2 ? (int64_t)g * n_waves + gwave : gwave * RPW + g;
         if (dg <= 256) {
             // up to 4 edges per lane: the row's scores (8 heads at a time) stay in registers -- columns and values
             // requested together, then the score rows, then maximum, sum and weights without another read
