@@ -12,6 +12,8 @@
 // added in slab order by a second kernel (bitwise reproducible, no atomics).
 #include "sgx_internal.h"
 
+#include <stdlib.h>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -76,6 +78,84 @@ __global__ __launch_bounds__(kBlock) void xtg_partial_kernel(
             }
 }
 
+// The same partial products with ONE 16-byte load per lane and operand (8 bytes of halves) instead of four 4-byte ones:
+// lane l15 takes columns 4 l15 .. 4 l15 + 3 of its tile and element t feeds MFMA tile t, i.e. MFMA row r of tile t stands
+// for column 4 r + t -- a permutation of the 64 columns inside the wavefront's tile, undone in the stores (which become
+// 16 bytes per lane too).  Loads through buffer resources: rows past the slab's end and columns past the table read as
+// zero without a branch.  Every output still sums its graph rows in the same order: the same bits as the scalar kernel.
+// (Reddit shape, 602 x 128: 0.67 -> see profiles; the scalar kernel stays for tables over 4 GiB or unaligned rows.)
+typedef unsigned int xtg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int xtg_u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kXtgOob = 0xFFFFFFF0u;
+
+template <typename TX>
+__global__ __launch_bounds__(kBlock) void xtg_partial_vec_kernel(
+    int n_rows, int M, int P, const TX *__restrict__ X, unsigned ldx_bytes, const float *__restrict__ G, unsigned ldg_bytes,
+    float *__restrict__ partial, int n_slabs, int rows_per_slab, int m_pad, int p_pad)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int slab = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (slab >= n_slabs) return;
+    const int m0 = blockIdx.y * kTile, p0 = blockIdx.z * kTile;
+    const int64_t n_begin = (int64_t)slab * rows_per_slab;
+    const int64_t n_end = n_begin + rows_per_slab < n_rows ? n_begin + rows_per_slab : n_rows;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<TX *>(X), 0, (unsigned)n_rows * ldx_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G), 0, (unsigned)n_rows * ldg_bytes, 0x00020000);
+    const int ma = m0 + 4 * l15, pa = p0 + 4 * l15;                 // this lane's first column of X and of G
+    const unsigned x_col = ma < M ? (unsigned)ma * (unsigned)sizeof(TX) : kXtgOob;
+    const unsigned g_col = pa < P ? (unsigned)pa * 4u : kXtgOob;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+
+    for (int64_t n0 = n_begin; n0 < n_end; n0 += 4 * kUnroll) {
+        float a[kUnroll][4], b[kUnroll][4];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t n = n0 + 4 * u + lq;
+            const bool ok = n < n_end;
+            const unsigned xo = (ok && x_col != kXtgOob) ? (unsigned)n * ldx_bytes + x_col : kXtgOob;
+            const unsigned go = (ok && g_col != kXtgOob) ? (unsigned)n * ldg_bytes + g_col : kXtgOob;
+            if constexpr (sizeof(TX) == 2) {
+                union { xtg_u32x2 v; f16 h[4]; } ux;
+                ux.v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, xo, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[u][t] = ma + t < M ? (float)ux.h[t] : 0.0f;
+            } else {
+                union { xtg_u32x4 v; float f[4]; } ux;
+                ux.v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[u][t] = ma + t < M ? ux.f[t] : 0.0f;
+            }
+            union { xtg_u32x4 v; float f[4]; } ug;
+            ug.v = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, go, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[u][t] = pa + t < P ? ug.f[t] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    }
+    // C/D layout: column = lane & 15 = B's row index (p = p0 + 4 (lane & 15) + j), row = 4 (lane >> 4) + reg = A's row
+    // index (m = m0 + 4 row + i): a lane holds 4 consecutive p of one m per (i, reg)
+    float *out = partial + (size_t)slab * m_pad * p_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * (4 * lq + r) + i;
+            *reinterpret_cast<f32x4 *>(out + (size_t)m * p_pad + pa) = (f32x4){acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        }
+}
+
 __global__ __launch_bounds__(kBlock) void xtg_reduce_kernel(int M, int P, const float *__restrict__ partial, int n_slabs,
                                                             int m_pad, int p_pad, float *__restrict__ out, int64_t ldo)
 {
@@ -133,7 +213,19 @@ extern "C" int sgx_xt_g(int dtype_x, int n_rows, int M, int P, const void *X, in
     if (!workspace || workspace_bytes < (size_t)g.n_slabs * g.m_pad * g.p_pad * sizeof(float)) return SGX_ERR_WORKSPACE;
     float *partial = (float *)workspace;
     dim3 grid((g.n_slabs + kBlock / 64 - 1) / (kBlock / 64), g.m_pad / kTile, g.p_pad / kTile);
-    if (dtype_x == SGX_F16)
+    // 16-byte loads (8 bytes of halves) where the rows are dword-aligned and the tables fit 32-bit offsets
+    const size_t es = dtype_x == SGX_F16 ? 2 : 4;
+    const bool vec = !getenv("SGX_XTG_SCALAR") && ((uintptr_t)X % 4 == 0) && ((ldx * es) % 4 == 0) && ((uintptr_t)G % 16 == 0) &&
+                     ((ldg * 4) % 16 == 0) && (dtype_x == SGX_F16 ? (ldx * es) % 8 == 0 && (uintptr_t)X % 8 == 0 : (ldx * es) % 16 == 0 && (uintptr_t)X % 16 == 0) &&
+                     (unsigned long long)n_rows * ldx * es < 0xFFF00000ull && (unsigned long long)n_rows * ldg * 4ull < 0xFFF00000ull;
+    if (vec) {
+        if (dtype_x == SGX_F16)
+            hipLaunchKernelGGL(xtg_partial_vec_kernel<f16>, grid, dim3(kBlock), 0, s, n_rows, M, P, (const f16 *)X, (unsigned)(ldx * 2), G,
+                               (unsigned)(ldg * 4), partial, g.n_slabs, g.rows_per_slab, g.m_pad, g.p_pad);
+        else
+            hipLaunchKernelGGL(xtg_partial_vec_kernel<float>, grid, dim3(kBlock), 0, s, n_rows, M, P, (const float *)X, (unsigned)(ldx * 4), G,
+                               (unsigned)(ldg * 4), partial, g.n_slabs, g.rows_per_slab, g.m_pad, g.p_pad);
+    } else if (dtype_x == SGX_F16)
         hipLaunchKernelGGL(xtg_partial_kernel<f16>, grid, dim3(kBlock), 0, s, n_rows, M, P, (const f16 *)X, ldx, G, ldg,
                            partial, g.n_slabs, g.rows_per_slab, g.m_pad, g.p_pad);
     else

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("xdtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("n,M,P", [(5000, 64, 64), (100003, 64, 64), (4097, 7, 64), (3000, 100, 256), (2000, 1433, 16),
-                                   (777, 65, 7)])
+                                   (777, 65, 7), (40001, 602, 128), (9000, 128, 256), (5001, 36, 20)])
 def test_xt_g_matches_fp64(xdtype, n, M, P):
     from sgracex1_amd import ops
     g = torch.Generator(device="cuda")
@@ -24,6 +24,14 @@ def test_xt_g_matches_fp64(xdtype, n, M, P):
     assert ((got.double() - want).abs() / scale).max() < 5e-6
     again = ops.xt_g(X, G)
     assert torch.equal(got, again)                               # slab sums are order-fixed
+    # the 16-byte-load kernel (aligned rows) and the scalar one it stands beside: every output sums its rows in the same order
+    import os
+    os.environ["SGX_XTG_SCALAR"] = "1"
+    try:
+        scalar = ops.xt_g(X, G)
+    finally:
+        del os.environ["SGX_XTG_SCALAR"]
+    assert torch.equal(got, scalar)
 
 
 def test_csr_transpose_bit_exact():
