@@ -314,8 +314,9 @@ constexpr int kW32Threads = 512;
 template <int KB, int NT>
 __global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
     int n_rows, int M, int P, const float *__restrict__ X, int64_t ldx, const float *__restrict__ Wt, int64_t ldw,
-    float *__restrict__ H, int64_t ldh, int h_aligned, sgx_epilogue ep, int relu)
+    float *__restrict__ H, int64_t ldh, int n_out, int h_aligned, sgx_epilogue ep, int relu)
 {
+    // (n_out: the columns this launch produces -- its block of a wider output; ldh stays the pitch of H)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw32[];
     float *sW = reinterpret_cast<float *>(lds_raw32);            // [16 NT][LP]
     constexpr int LP = 16 * KB + 4;                              // floats per LDS row: (LP / 4) odd
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
         constexpr int kFill = 8;
         constexpr int cpr = LP / 4, total = 16 * NT * cpr;
         const __amdgpu_buffer_rsrc_t w_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0, (unsigned)(((int64_t)(P - 1) * ldw + M) * 4), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wt), 0, P > 0 ? (unsigned)(((int64_t)(P - 1) * ldw + M) * 4) : 0u, 0x00020000);
         for (int c0 = tid; c0 < total; c0 += kW32Threads * kFill) {
             u32x4 v[kFill];
             int kk[kFill];
@@ -413,19 +414,19 @@ __global__ __launch_bounds__(kW32Threads) void xw_dense_wlds_f32_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[nt][j] = acc[nt][j] > 0.0f ? acc[nt][j] : 0.0f;
             }
-            if (h_aligned && n + 4 <= ldh) {
+            if (h_aligned && n + 4 <= n_out) {
                 *reinterpret_cast<f32x4 *>(dst) = acc[nt];
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (n + j < ldh) dst[j] = acc[nt][j];
+                    if (n + j < n_out) dst[j] = acc[nt][j];
             }
         }
     }
 }
 
 template <int KB, int NT>
-int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
+int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh, int n_out,
                     int ha, sgx_epilogue ep, int relu, hipStream_t s)
 {
     auto kernel = xw_dense_wlds_f32_kernel<KB, NT>;
@@ -445,7 +446,7 @@ int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const 
     const int64_t want = (tiles + kW32Threads / 64 - 1) / (kW32Threads / 64);
     if (want < grid) grid = want;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kW32Threads), lds_bytes, s, n_rows, M, P, (const float *)X, ldx,
-                       (const float *)Wt, ldw, (float *)H, ldh, ha, ep, relu);
+                       (const float *)Wt, ldw, (float *)H, ldh, n_out, ha, ep, relu);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
@@ -458,14 +459,25 @@ int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, 
 {
     if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning / test override, read per call
     const int cols = (int)ldh;                                          // pad columns are produced (as zeros) too
-    // wide outputs only: with few column tiles the register-stationary kernel reads X once as well
-    if (M > 128 || M <= 32 || cols <= 64 || cols > 256 || n_rows < 32768) return SGX_ERR_UNSUPPORTED;
+    // wide outputs only: with few column tiles the register-stationary kernel reads X once as well; more than 256 columns
+    // go in blocks of 256 (X re-read per block: 602 columns of the backward's g . W^T = 3 passes instead of the 10 of the
+    // register-stationary kernel's column groups)
+    if (M > 128 || M <= 32 || cols <= 64 || cols > 1024 || n_rows < 32768) return SGX_ERR_UNSUPPORTED;
     if ((uint64_t)P * (uint64_t)ldw * 4ull >= 0xFFF00000ull || (ldw & 3) || ((uintptr_t)Wt & 15)) return SGX_ERR_UNSUPPORTED;
     const int kb = (M + 15) / 16 <= 4 ? 4 : 8;
-    const int nt = cols <= 128 ? 8 : 16;
-#define SGX_W32(KB_, NT_) return launch_wlds_f32<KB_, NT_>(n_rows, M, P, X, ldx, Wt, ldw, H, ldh, h_aligned, ep, relu, stream)
-    if (kb == 4) { if (nt == 8) SGX_W32(4, 8); SGX_W32(4, 16); }
-    if (nt == 8) SGX_W32(8, 8);
-    SGX_W32(8, 16);
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int n_out = cols - c0 < 256 ? cols - c0 : 256;
+        const int p_blk = P - c0 < 0 ? 0 : (P - c0 < 256 ? P - c0 : 256);
+        const float *w_blk = (const float *)Wt + (int64_t)c0 * ldw;
+        float *h_blk = (float *)H + c0;
+        const int ha = h_aligned && ((uintptr_t)h_blk % 16 == 0);
+        int rc;
+        if (p_blk == 0) w_blk = (const float *)Wt;                      // (only pad columns left: every row of the block reads as zero)
+#define SGX_W32(KB_, NT_) rc = launch_wlds_f32<KB_, NT_>(n_rows, M, p_blk, X, ldx, w_blk, ldw, h_blk, ldh, n_out, ha, ep, relu, stream)
+        if (kb == 4) { if (n_out <= 128) SGX_W32(4, 8); else SGX_W32(4, 16); }
+        else { if (n_out <= 128) SGX_W32(8, 8); else SGX_W32(8, 16); }
 #undef SGX_W32
+        if (rc != SGX_OK) return rc;
+    }
+    return SGX_OK;
 }

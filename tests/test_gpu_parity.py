@@ -746,7 +746,7 @@ def test_xw_dense_fp32_weights_in_registers(M, P):
     assert not base[:, P:].any()
 
 
-@pytest.mark.parametrize("M,P", [(128, 256), (100, 250), (48, 128), (128, 65), (64, 256), (33, 129)])
+@pytest.mark.parametrize("M,P", [(128, 256), (100, 250), (48, 128), (128, 65), (64, 256), (33, 129), (128, 602), (64, 300), (128, 770)])
 def test_xw_dense_fp32_weights_in_lds(M, P):
     """fp32 X.W, K <= 128, more than 64 output columns, 32 K rows and more: all of W^T in LDS and every wavefront on all
     column tiles of its row tiles (xw_dense_wlds_f32_kernel) against the tile kernel -- the same sums in the same order,
