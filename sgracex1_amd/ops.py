@@ -206,8 +206,10 @@ class Csr:
         return self._plan is not None or self.nnz >= 8192
 
     def to(self, dtype):
+        # (the schedule depends on rowptr only: the copy shares this matrix's -- built here if it is wanted and not there
+        # yet, so that a copy made per training step does not build one per step)
         return self if self.val.dtype == dtype else Csr(self.rowptr, self.col, self.val.to(dtype), self.n_cols,
-                                                        self._plan)
+                                                        self.plan if self.wants_plan else None)
 
     def validate(self):
         check(lib.sgx_csr_validate(_ptr(self.rowptr), _ptr(self.col), self.n_rows, self.n_cols, self.nnz, _stream()),

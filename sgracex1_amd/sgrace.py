@@ -202,7 +202,7 @@ class FPYNQ_GAT(torch.autograd.Function):
         A = ctx.csr
         if ctx.gat:
             E, S = saved[3], saved[4]
-            P = ops.Csr(A.rowptr, A.col, S.contiguous(), A.n_cols, A._plan)       # attention matrix, fp32 values
+            P = ops.Csr(A.rowptr, A.col, S.contiguous(), A.n_cols, A.plan if A.wants_plan else None)   # attention matrix, fp32 values; A's schedule
             Wh = ops.xw_dense(input.contiguous(), weights.t().contiguous())       # X . W, fp32 (SG.py:601); rows padded to 16 B
             sg, g1 = ops.gat_backward_edges(A, E, S, g.contiguous(), Wh, ctx.alpha)
             # column sums of sg = row sums over A^T; the transposed pattern is built once per graph
