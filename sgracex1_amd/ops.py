@@ -620,6 +620,11 @@ def csr_transpose(A, return_order=False):
     order = torch.argsort(key)
     T = Csr.from_coo(col[order].contiguous(), row[order].to(torch.int32).contiguous(), val[order].contiguous(),
                      A.n_cols, A.n_rows)
+    if T.n_rows > 0 and T.nnz >= 64 * T.n_rows:
+        # a feature matrix transposed: a handful of rows, each as long as the graph is wide (MUTAG: 7 rows of ~500 entries) --
+        # below the size at which a plan is built by itself, and exactly the shape that needs one: without it 7 lane groups
+        # walk 60 dependent steps each (58 us for a 3.4 K-entry matrix) where the plan's 64-edge tasks take a few
+        T.plan
     return (T, order) if return_order else T
 
 
