@@ -1149,11 +1149,25 @@ __global__ __launch_bounds__(kBlock) void gat_scores_rows_kernel(int n_rows, int
     const bool mine = col0 < n_feat;
     const int h = mine ? col0 / f_head : 0, j0 = mine ? col0 - h * f_head : 0;
     const int lanes_per_head = f_head / VEC;
+    // the lane's fragments of the attention vectors: one 16-byte load each where they are aligned (element loads were
+    // 2 VEC memory instructions per wavefront ahead of its 4 row loads -- with one wavefront per 8 rows, most of the kernel)
     float a1[VEC], a2[VEC];
+    const T *p1 = att + (int64_t)h * 2 * f_head + j0, *p2 = p1 + f_head;
+    if (((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) % 16) == 0 && VEC * sizeof(T) == 16) {
+        union { u32x4 v; T e[VEC]; } u1, u2;
+        u1.v = mine ? *reinterpret_cast<const u32x4 *>(p1) : u32x4{0u, 0u, 0u, 0u};
+        u2.v = mine ? *reinterpret_cast<const u32x4 *>(p2) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        a1[i] = mine ? Elem<T>::to_f32(att[(int64_t)h * 2 * f_head + j0 + i]) : 0.0f;
-        a2[i] = mine ? Elem<T>::to_f32(att[(int64_t)h * 2 * f_head + f_head + j0 + i]) : 0.0f;
+        for (int i = 0; i < VEC; ++i) {
+            a1[i] = mine ? Elem<T>::to_f32(u1.e[i]) : 0.0f;
+            a2[i] = mine ? Elem<T>::to_f32(u2.e[i]) : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            a1[i] = mine ? Elem<T>::to_f32(p1[i]) : 0.0f;
+            a2[i] = mine ? Elem<T>::to_f32(p2[i]) : 0.0f;
+        }
     }
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
@@ -1503,7 +1517,7 @@ int gat_two_stage(const GatArgs &a)
         (lanes_per_head & (lanes_per_head - 1)) == 0 &&
         (unsigned long long)a.n_cols * (unsigned long long)a.ldh * sizeof(T) < 0xFFF00000ull) {       // (32-bit buffer offsets)
         int64_t blocks = ((int64_t)a.n_cols + rows_per_block - 1) / rows_per_block;
-        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL((gat_scores_rows_kernel<T, VEC, LPR>), dim3((unsigned)blocks), dim3(kBlock), 0, a.stream, a.n_cols,
                            a.n_feat, a.n_heads, f_head, (const T *)a.Wh, a.ldh, (const T *)a.att, s1, s2);
     } else if (a.n_heads > 1) {

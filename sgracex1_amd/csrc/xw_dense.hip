@@ -258,10 +258,12 @@ __global__ __launch_bounds__(kBlock) void xw_dense_stationary_f16_kernel(
         for (int q = 0; q < NTW / 2; ++q) {
             const int c0 = n_base + 32 * q + 8 * lq;                 // this lane's first column of the pair
             const int head = c0 / f_head, j0 = c0 - head * f_head;
+            const f16x8 v1 = load_k8(att + (int64_t)head * 2 * f_head, j0, f_head, head < n_heads, true);             // (one 16-byte load)
+            const f16x8 v2 = load_k8(att + (int64_t)head * 2 * f_head + f_head, j0, f_head, head < n_heads, true);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                att1[q][j] = head < n_heads ? (float)att[(int64_t)head * 2 * f_head + j0 + j] : 0.0f;
-                att2[q][j] = head < n_heads ? (float)att[(int64_t)head * 2 * f_head + f_head + j0 + j] : 0.0f;
+                att1[q][j] = (float)v1[j];
+                att2[q][j] = (float)v2[j];
             }
         }
     }
