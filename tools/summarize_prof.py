@@ -105,7 +105,9 @@ def main():
     others = {}
     for label, sub in (("xw_sparse_lds_kernel (X.W, CSR X, layer 1, weight slice in LDS)", "xw_sparse_lds_kernel"),
                        ("xw_sparse_kernel (X.W, CSR X, layer 1, gathered through L2)", "xw_sparse_kernel"),
-                       ("xw_dense (X.W, dense X, layer 2)", "xw_dense")):
+                       ("xw_dense_wlds_f16_kernel (X.W, dense X, long K, W^T in LDS)", "xw_dense_wlds_f16"),
+                       ("xw_dense_stationary_f16_kernel (X.W, dense X, K <= 128, W fragments in registers)", "xw_dense_stationary_f16"),
+                       ("xw_dense (other dense X.W kernels)", "xw_dense_f")):
         f_, w_ = counter(fetch_all, sub, "FETCH_SIZE"), counter(write_all, sub, "WRITE_SIZE")
         h_, m_ = counter(l2, sub, "TCC_HIT_sum"), counter(l2, sub, "TCC_MISS_sum")
         if f_:
