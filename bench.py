@@ -11,7 +11,9 @@ BASELINE.json's target is quoted on: S-100M -- N = 2^22 nodes, 100 M uniformly r
 edges (+ self loops, coalesced), GCN symmetric normalisation, fp16, hidden = 64, Cora-like
 sparse input features (F_in = 1433, density 1.27 %).  Output: ONE JSON line on rank 0.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a
+N > 1 (one rank per GPU; `python bench.py --gpus N` starts the ranks itself as a child `torch.distributed.run`, and a
+rank started by the driver's own `python -m torch.distributed.run ... bench.py --gpus N` finds WORLD_SIZE set and just
+runs): weak scaling -- every rank owns a
 partition of 2^22 rows / 100 M edges of a graph with N * 2^22 nodes; --cut (default 0.1) of a
 partition's edges leave it and land on the boundary nodes (--boundary, default 0.2 of the rows) of
 the other partitions, the rest stay inside it -- the shape a graph partitioner leaves behind (N = 1
@@ -59,6 +61,12 @@ def parse():
     ap.add_argument("--exchange", choices=("halo-overlap", "halo", "allgather"), default=None,
                     help="N > 1: rows of H exchanged per layer (default: halo-overlap = halo rows travel while the "
                          "own-partition edges are aggregated; allgather when --cut >= 0.5)")
+    ap.add_argument("--no-rmat-leg", action="store_true",
+                    help="N = 1, workload s100m: skip the power-law (R-MAT) variant of the aggregation launch that is timed "
+                         "after the step and reported as roofline_rmat (outside `value`)")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="--gpus N > 1 started without torch.distributed.run: seconds the ranks get before the parent ends "
+                         "them and prints an error line")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="rocprofv3 --pmc result for the dominant kernel (HBM bytes per launch)")
     return ap.parse_args()
@@ -240,6 +248,55 @@ def cpu_reference_formulation(torch, ops, A, X, W1t, W2t, frac, budget_s=12.0):
     return out
 
 
+def rmat_leg(torch, graphs, ops, Event, wl, device, stream, launches, warmup):
+    """The power-law variant (p) of S-100M (R-MAT .57/.19/.19/.05, seed 12345), aggregation launch only:
+    D = relu(A . H) at the same N / edges / hidden, timed by HIP events on the launch stream AFTER the step's timed region
+    and reported as `roofline_rmat` -- never part of `value`.  The measured-bytes fraction quotes the committed counter
+    passes of this workload (counters need their own rocprofv3 --pmc runs), with its source named."""
+    n, hidden = wl["n"], wl["hidden"]
+    A = graphs.rmat_graph(n.bit_length() - 1, wl["edges"], seed=12345, device=device)
+    A.plan
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    H = torch.rand((n, hidden), generator=g, device=device).half()
+    D = torch.empty((n, hidden), dtype=torch.float16, device=device)
+    for _ in range(warmup):
+        ops.spmm(A, H, relu=True, out=D)
+    pairs = [(Event(), Event()) for _ in range(launches)]
+    for b, e in pairs:
+        b.record(stream)
+        ops.spmm(A, H, relu=True, out=D)
+        e.record(stream)
+    torch.cuda.synchronize()
+    ms = sorted(b.elapsed_ms(e) for b, e in pairs)
+    avg = sum(ms) / len(ms)
+    nnz = A.nnz
+    b_alg = nnz * (4 + 2 + hidden * 2) + (n + 1) * 4 + n * hidden * 2
+    deg = (A.rowptr[1:] - A.rowptr[:-1])
+    out = {"workload": "s100m-rmat", "generator": "rmat a/b/c/d=.57/.19/.19/.05 seed 12345", "nodes": n, "edges": nnz,
+           "hidden": hidden, "max_degree": int(deg.max().item()), "plan_long_rows": A.plan.long_rows,
+           "plan_long_threshold": A.plan.long_threshold, "plan_reordered": A.plan.reordered,
+           "kernel": "spmm_kernel<f16,8,8> + long-row tasks + spmm_split_finalize_kernel (A.H aggregation, events bracket all of it)",
+           "avg_launch_ms": avg, "min_launch_ms": ms[0], "launches_timed": len(ms),
+           "algorithmic_bytes_per_launch": b_alg, "achieved": b_alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": b_alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "agg_edges_per_s": nnz / (avg * 1e-3),
+           "traffic": None, "traffic_source": None, "frac_measured_bytes": None}
+    tf_path = os.path.join(ROOT, "profiles", "traffic_s100m-rmat.json")
+    if os.path.exists(tf_path):
+        try:
+            tf = json.load(open(tf_path))
+            out["traffic"] = tf.get("hbm_bytes_per_launch")
+            out["traffic_source"] = (f"offline rocprofv3 --pmc passes of this workload, {tf.get('source')} (tag {tf.get('tag')}); "
+                                     "not collected in this run")
+            if out["traffic"]:
+                # the binding number where cache hits make the memory side move fewer bytes than the gather model counts
+                out["frac_measured_bytes"] = out["traffic"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS
+        except (ValueError, OSError):
+            pass
+    del A, H, D
+    return out
+
+
 def device_identity(torch, device):
     """What tells one GPU of the node from another in the bench line: host, index, name, PCI bus / uuid where torch has them."""
     import socket
@@ -252,14 +309,135 @@ def device_identity(torch, device):
     return " ".join(str(x) for x in parts)
 
 
+_WHERE = ["start"]
+
+
 def note(msg):
-    """progress on stderr (SGX_BENCH_VERBOSE=1): where a multi-rank rehearsal is when it is slow or stuck"""
+    """progress on stderr (SGX_BENCH_VERBOSE=1): where a multi-rank rehearsal is when it is slow or stuck; the last note
+    also goes into the error line of a rank that fails"""
+    _WHERE[0] = msg
     if os.environ.get("SGX_BENCH_VERBOSE"):
         print(f"[bench {os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def emit(obj):
+    """One line on stdout in ONE write (line and newline together): the ranks of a job share the pipe, and two prints that
+    interleave between text and newline give the reader one unparsable line."""
+    sys.stdout.flush()
+    os.write(1, (json.dumps(obj) + "\n").encode())
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process only PARENTS the ranks.  It starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child process (subprocess -- never an
+    exec, and nothing here imports torch or touches the GPU), passes the ranks' stderr through, and prints exactly ONE line
+    on stdout: rank 0's result line, or -- whatever ended the run (a rank's exception, a rank killed from outside, the
+    time limit) -- an {"error": ...} line with the child's return code and the tail of its stderr.  Returns the exit code."""
+    import collections
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on these hosts
+    t0 = time.time()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, bufsize=1,
+                             start_new_session=True)
+    results, rank_errors, tail = [], [], collections.deque(maxlen=40)
+
+    def pump_out():
+        for ln in child.stdout:
+            ln = ln.rstrip("\n")
+            obj = None
+            if ln.startswith("{"):
+                try:
+                    obj = json.loads(ln)
+                except ValueError:
+                    obj = None
+            if isinstance(obj, dict) and "metric" in obj and "value" in obj:
+                results.append(ln)
+            elif isinstance(obj, dict) and "error" in obj:
+                rank_errors.append(obj)
+            elif ln:
+                print(ln, file=sys.stderr, flush=True)          # library chatter ("[Gloo] Rank 0 is connected ...")
+
+    def pump_err():
+        for ln in child.stderr:
+            tail.append(ln.rstrip("\n"))
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+
+    threads = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for t in threads:
+        t.start()
+    timed_out = False
+    try:
+        rc = child.wait(timeout=args.rank_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig, grace in ((signal.SIGTERM, 15), (signal.SIGKILL, 15)):
+            try:
+                os.killpg(child.pid, sig)                        # the child's own session: the launcher and its ranks, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = child.poll() if child.poll() is not None else -9
+    for t in threads:
+        t.join(timeout=10)
+    report = os.environ.get("SGX_BENCH_PARENT_REPORT")
+    if report:                                                   # for tests: what the parent did and did not do
+        with open(report, "w") as f:
+            json.dump({"cmd": cmd, "rc": rc, "timed_out": timed_out, "torch_imported": "torch" in sys.modules, "child_pid": child.pid,
+                       "seconds": time.time() - t0}, f)
+    if rc == 0 and len(results) == 1:
+        print(results[0], flush=True)
+        return 0
+    why = (f"the ranks did not finish within --rank-timeout {args.rank_timeout:.0f} s and were ended" if timed_out else
+           f"torch.distributed.run ended with return code {rc}" if rc != 0 else
+           f"the ranks ended with return code 0 but printed {len(results)} result lines")
+    print(json.dumps({"error": why, "n_gpus": args.gpus, "rc": rc, "timed_out": timed_out, "rank_errors": rank_errors,
+                      "result_lines_seen": len(results), "stderr_tail": list(tail)[-25:], "cmd": cmd}), flush=True)
+    return rc if rc not in (0, None) else 1
+
+
 def main():
+    """Entry: parent of the ranks (above), or one rank.  A rank that fails prints its traceback on stderr and ONE
+    {"error": ..., "rank": ...} line on stdout and exits non-zero -- an N > 1 run never ends without a line."""
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    try:
+        run(args)
+    except SystemExit:
+        raise
+    except BaseException as exc:              # noqa: BLE001 -- KeyboardInterrupt included: say so before going down
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        emit({"error": f"{type(exc).__name__}: {exc}", "rank": int(os.environ.get("RANK", "0")),
+              "world_size": int(os.environ.get("WORLD_SIZE", "1")), "where": _WHERE[0]})
+        sys.exit(1)
+
+
+def run(args):
+    # test hooks: a rank that raises / a rank that is killed from outside (no traceback, no line of its own)
+    if os.environ.get("SGX_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise RuntimeError("injected failure of this rank")
+    if os.environ.get("SGX_BENCH_TEST_DIE_RANK") == os.environ.get("RANK", "0"):
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
+    if os.environ.get("SGX_BENCH_TEST_HANG_RANK") in (os.environ.get("RANK", "0"), "all"):
+        time.sleep(3600)
     import torch
     import torch.distributed as dist
     from sgracex1_amd import dist as sdist
@@ -269,10 +447,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world                       # under torch.distributed.run the launcher's rank count is the truth
     device = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
@@ -283,6 +458,7 @@ def main():
         else:
             dist.init_process_group(backend_name)
 
+    note("process group up" if world > 1 else "device set")
     # what the line must prove for N > 1: the backend that actually carried the exchange, the number of ranks IT sees,
     # and one identity per rank (distinct devices = the ranks really sat on different GPUs)
     dist_backend = dist.get_backend() if world > 1 else None
@@ -564,6 +740,9 @@ def main():
     if exchange_stats is not None:
         line["exchange"] = exchange_stats
         line["exchange_allgather"] = allgather_stats
+    if world == 1 and args.workload == "s100m" and not args.no_rmat_leg and not args.exact:
+        note("power-law leg")
+        line["roofline_rmat"] = rmat_leg(torch, graphs, ops, Event, wl, device, stream, max(5, min(args.steps, 20)), 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, ops, A, X, W1t, W2t, args.cpu_sample_frac)
         line["cpu_baseline"]["reference_formulation"] = cpu_reference_formulation(torch, ops, A, X, W1t, W2t,
@@ -571,7 +750,7 @@ def main():
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 

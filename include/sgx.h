@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 105
+#define SGX_VERSION 106
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -392,6 +392,11 @@ int sgx_event_elapsed_ms(void *begin, void *end, float *ms);
 
 int         sgx_version(void);
 const char *sgx_status_string(int status);
+
+/* The library reads its SGX_* tuning overrides from the environment once, at its first use.  A process that changes one
+ * of them later (a test comparing two kernel forms) calls this to have them read again.  Not for concurrent use with
+ * other calls into the library. */
+void sgx_reload_env(void);
 
 #ifdef __cplusplus
 }

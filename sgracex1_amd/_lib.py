@@ -32,7 +32,7 @@ SYMBOLS = [
     "sgx_stream_copy", "sgx_xw_dense_act", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_gat_aggregate_fill", "sgx_col_sums", "sgx_col_sums_scratch_bytes", "sgx_pack_rows",
     "sgx_code_bias", "sgx_quantize_codes_i8", "sgx_xw_dense_i8", "sgx_xw_dense_i8_workspace_bytes",
-    "sgx_version", "sgx_status_string",
+    "sgx_version", "sgx_status_string", "sgx_reload_env",
 ]
 
 
@@ -178,6 +178,8 @@ def _load():
     lib.sgx_version.restype = c_int
     lib.sgx_status_string.argtypes = [c_int]
     lib.sgx_status_string.restype = ctypes.c_char_p
+    lib.sgx_reload_env.argtypes = []
+    lib.sgx_reload_env.restype = None
     return lib
 
 
@@ -191,3 +193,30 @@ def status_string(status):
 def check(status, where):
     if status != 0:
         raise SgxError(status, where)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def tuning(**overrides):
+    """Run a block under SGX_* tuning overrides: `with tuning(SGX_XW_NO_WLDS="1"): ...`.  The library reads its
+    overrides from the environment once per process (include/sgx.h, sgx_reload_env), so changing os.environ alone does
+    nothing after the first call; this sets the variables, has the library read them again, and undoes both on the way
+    out.  A value of None removes the variable for the block.  For tests and probes that compare two forms of a kernel."""
+    saved = {k: os.environ.get(k) for k in overrides}
+    try:
+        for k, v in overrides.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        lib.sgx_reload_env()
+        yield
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        lib.sgx_reload_env()

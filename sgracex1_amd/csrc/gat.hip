@@ -1618,7 +1618,7 @@ size_t split_floats(const sgx_plan *plan, int n_feat, int n_heads)
 // the two-stage form needs the stored-entry count on the host (a plan carries it) and 32-bit offsets into the weights
 bool two_stage_ok(const sgx_plan *plan, int n_heads)
 {
-    if (getenv("SGX_GAT_ONE_PASS")) return false;           // tuning override: the one-pass kernels
+    if (sgx_tune().gat_one_pass) return false;           // tuning override: the one-pass kernels
     return plan && plan->nnz > 0 && (unsigned long long)plan->nnz * (unsigned long long)n_heads < (1ull << 30) &&
            (unsigned long long)plan->n_rows * (unsigned long long)n_heads < (1ull << 30);
 }
@@ -1634,7 +1634,7 @@ size_t two_stage_floats(const sgx_plan *plan, int n_heads)
 bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan)
 {
     if (n_heads < 1) n_heads = 1;
-    if (dtype != SGX_F16 || n_feat % n_heads != 0 || n_feat % 64 != 0 || !two_stage_ok(plan, n_heads) || getenv("SGX_GAT_NO_FUSED_SCORES"))
+    if (dtype != SGX_F16 || n_feat % n_heads != 0 || n_feat % 64 != 0 || !two_stage_ok(plan, n_heads) || sgx_tune().gat_no_fused_scores)
         return false;
     const int f_head = n_feat / n_heads;
     return f_head == 32 || f_head % 64 == 0;         // a head = a lane quad's pair of tiles, or whole 64-column groups of a wavefront

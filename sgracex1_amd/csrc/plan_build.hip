@@ -3,10 +3,11 @@
 // The reference decides on the host, once per matrix, how rows are split over ADJ_THREADS / FEA_THREADS and grouped
 // per pipelined loop (K.cpp:3517-3523, :826-845; MM.h:166-191).  Here the same two decisions -- which rows are cut
 // into edge tasks, and whether the others are walked in degree order -- are made from rowPtr where it lies, in HBM:
-// the host reads back 4 bytes (the entry count, which picks the cut) and then 24 bytes (how many long rows and tasks
+// the host reads back 40 bytes ONCE (the entry count, the cut the device picked from it, how many long rows and tasks
 // there are, to size the arrays, and the lane-group utilisation of the natural order), never rowPtr itself.  A
-// sampled mini-batch (the demo's NeighborLoader call pattern) pays two stream synchronisations of a few microseconds
-// per adjacency instead of a copy of rowPtr and three passes over it on one host core.
+// sampled mini-batch (the demo's NeighborLoader call pattern) pays one stream synchronisation of a few microseconds
+// per adjacency (a second one at the end only when kernels follow the read-back: long rows or the degree order)
+// instead of a copy of rowPtr and three passes over it on one host core.
 //
 //   count      per row: long? how many tasks? how many 8-edge steps?  per 8 consecutive rows: the longest's steps
 //              (what a wavefront that packs them spends).  Totals by atomics, long rows / tasks per row block.
@@ -26,8 +27,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 1024;          // row blocks: scanned by one workgroup in one pass
 
-const int kLongThreshold = 4096;
-const int kMaxCut = 1 << 16;            // the largest cut a caller may ask for
+constexpr int kLongThreshold = 4096;
+constexpr int kMaxCut = 1 << 16;            // the largest cut a caller may ask for
 // Rows with more edges than the threshold take the split path, in tasks of `chunk` edges.  Measured on the
 // R-MAT S-100M aggregation (threshold = chunk): 512: 2.20 ms, 1024-2048: 2.10, 3072: 2.00, 4096: 1.94,
 // 6144: 2.04, 8192: 2.32 -- a lane group walks a 4096-edge row in 512 steps while the degree-ordered schedule
@@ -37,7 +38,7 @@ const int kMaxCut = 1 << 16;            // the largest cut a caller may ask for
 // dependent steps are (tools/plan_cut_probe.py, R-MAT, cut / ms of the plain aggregate: 2.4 M edges 512 / 0.136 against
 // 4096 / 0.400; 7.5 M edges 1024 / 0.179 against 0.241; 29 M edges 2048 / 0.448 against 0.786; 104 M edges 4096): the
 // optimum follows sqrt(nnz) / 2 rounded down to a power of two, which is what default_cut returns.
-int default_cut(int64_t nnz)
+__host__ __device__ inline int default_cut(int64_t nnz)
 {
     int cut = 64;
     while (cut < kLongThreshold && (int64_t)(2 * cut) * (2 * cut) * 4 <= nnz) cut *= 2;      // 2 cut <= sqrt(nnz) / 2
@@ -46,15 +47,35 @@ int default_cut(int64_t nnz)
 // Small matrices finish in microseconds and their time IS the longest row's chain of dependent
 // steps (Cora: 168 edges = 21 steps on one lane group), so there rows are cut much earlier: a
 // 64-edge task is one step for every lane group of its wavefront.
-const int64_t kSmallNnz = 1 << 20;
-const int kSmallThreshold = 64, kSmallChunk = 64;
+constexpr int64_t kSmallNnz = 1 << 20;
+constexpr int kSmallThreshold = 64, kSmallChunk = 64;
 const float kReorderBelow = 0.7f; // natural-order lane-group utilisation below which rows are degree-ordered
 
 struct PlanCounts {
     unsigned long long useful;     // lane-group steps that do work, rows packed 8 to a wavefront in natural order
     unsigned long long spent;      // lane-group steps such wavefronts run for
     unsigned n_long, n_tasks;
+    int nnz, long_threshold, chunk, pad;      // the entry count the device read and the cut it picked from it (below)
 };
+
+// The cut depends on the entry count, which lives in HBM (rowPtr[n_rows]): the counting kernel reads it there and picks
+// the cut itself, so the host needs ONE read-back per plan (counts + entry count + cut), not one for the entry count
+// and a second for the counts.  caller_* = sgx_plan_create_ex's arguments, env_* = the tuning overrides (0 = unset).
+__host__ __device__ inline void resolve_cut(int64_t nnz, int caller_threshold, int caller_chunk, int env_threshold, int env_chunk,
+                                            int &long_threshold, int &chunk)
+{
+    const bool small = nnz < kSmallNnz;
+    long_threshold = small ? kSmallThreshold : default_cut(nnz);
+    chunk = small ? kSmallChunk : long_threshold;
+    if (!small && caller_threshold >= 8) {                            // the caller's cut (large matrices only)
+        long_threshold = caller_threshold / 8 * 8;
+        chunk = caller_chunk >= 8 ? caller_chunk / 8 * 8 : long_threshold;
+    }
+    if (env_threshold >= 8) long_threshold = chunk = env_threshold / 8 * 8;
+    if (env_chunk >= 8) chunk = env_chunk / 8 * 8;
+    if (long_threshold > kMaxCut) long_threshold = kMaxCut;           // (one LDS counter per step count in the degree order)
+    if (chunk > kMaxCut) chunk = kMaxCut;
+}
 
 __device__ __forceinline__ int wave_sum(int v)
 {
@@ -86,14 +107,23 @@ __device__ __forceinline__ int block_scan_inclusive(int v, int *wave_tot, int &t
 }
 
 __global__ __launch_bounds__(kThreads) void plan_count_kernel(const int32_t *__restrict__ rowptr, int n_rows, int rows_per_block,
-                                                              int long_threshold, int chunk, PlanCounts *__restrict__ totals,
+                                                              int caller_threshold, int caller_chunk, int env_threshold, int env_chunk,
+                                                              PlanCounts *__restrict__ totals,
                                                               int32_t *__restrict__ block_long, int32_t *__restrict__ block_tasks)
 {
     __shared__ unsigned long long s_useful, s_spent;
     __shared__ int s_long, s_tasks;
+    int long_threshold, chunk;
+    const int nnz = rowptr[n_rows];
+    resolve_cut(nnz, caller_threshold, caller_chunk, env_threshold, env_chunk, long_threshold, chunk);
     if (threadIdx.x == 0) {
         s_useful = s_spent = 0ull;
         s_long = s_tasks = 0;
+        if (blockIdx.x == 0) {
+            totals->nnz = nnz;
+            totals->long_threshold = long_threshold;
+            totals->chunk = chunk;
+        }
     }
     __syncthreads();
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
@@ -284,45 +314,23 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     if (long_threshold_arg < 0 || chunk_arg < 0) return SGX_ERR_SHAPE;
     if (n_rows < 0) return SGX_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    int32_t nnz32 = 0;
-    SGX_HIP_CHECK(hipMemcpyAsync(&nnz32, rowPtr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    SGX_HIP_CHECK(hipStreamSynchronize(s));
-    const int64_t nnz = nnz32;
-    const bool small = nnz < kSmallNnz;
-    int long_threshold = small ? kSmallThreshold : default_cut(nnz);
-    int chunk = small ? kSmallChunk : long_threshold;
-    if (!small && long_threshold_arg >= 8) {                          // the caller's cut (large matrices only)
-        long_threshold = long_threshold_arg / 8 * 8;
-        chunk = chunk_arg >= 8 ? chunk_arg / 8 * 8 : long_threshold;
-    }
-    if (const char *t = getenv("SGX_PLAN_LONG_THRESHOLD")) {          // tuning overrides (tools/plan_probe)
-        const int v = atoi(t);
-        if (v >= 8) long_threshold = chunk = v / 8 * 8;
-    }
-    if (const char *t = getenv("SGX_PLAN_CHUNK")) {
-        const int v = atoi(t);
-        if (v >= 8) chunk = v / 8 * 8;
-    }
-    if (long_threshold > kMaxCut) long_threshold = kMaxCut;          // (one LDS counter per step count in the degree order)
-    if (chunk > kMaxCut) chunk = kMaxCut;
+    const sgx_tuning &tune = sgx_tune();
 
     // row blocks: whole multiples of the workgroup, at most kMaxBlocks of them
     int64_t rows_per_block64 = 4096;
     while ((n_rows + rows_per_block64 - 1) / rows_per_block64 > kMaxBlocks) rows_per_block64 *= 2;
     const int rows_per_block = (int)rows_per_block64;
     const int n_blocks = n_rows > 0 ? (int)((n_rows + rows_per_block64 - 1) / rows_per_block64) : 0;
-    const int steps_max = long_threshold / 8 + 1, n_buckets = steps_max + 1;
 
     sgx_plan *p = new sgx_plan();
     p->n_rows = n_rows;
-    p->nnz = nnz;
-    p->long_threshold = long_threshold;
-    p->chunk = chunk;
+    p->nnz = 0;
     p->n_long = p->n_tasks = 0;
     p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
     p->row_order = nullptr;
     p->n_ordered = 0;
     p->natural_utilization = 1.0f;
+    resolve_cut(0, long_threshold_arg, chunk_arg, tune.plan_long_threshold, tune.plan_chunk, p->long_threshold, p->chunk);
     if (n_blocks == 0) {
         *out = p;
         return SGX_OK;
@@ -339,16 +347,21 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     PlanCounts *totals = (PlanCounts *)counts_mem.p;
     int32_t *block_long = (int32_t *)(totals + 1), *block_tasks = block_long + n_blocks;
     SGX_HIP_CHECK(hipMemsetAsync(totals, 0, sizeof(PlanCounts), s));
-    hipLaunchKernelGGL(plan_count_kernel, dim3(n_blocks), dim3(kThreads), 0, s, rowPtr, n_rows, rows_per_block, long_threshold, chunk,
-                       totals, block_long, block_tasks);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(n_blocks), dim3(kThreads), 0, s, rowPtr, n_rows, rows_per_block, long_threshold_arg,
+                       chunk_arg, tune.plan_long_threshold, tune.plan_chunk, totals, block_long, block_tasks);
     SGX_LAUNCH_CHECK();
     PlanCounts host{};
     SGX_HIP_CHECK(hipMemcpyAsync(&host, totals, sizeof(PlanCounts), hipMemcpyDeviceToHost, s));
-    SGX_HIP_CHECK(hipStreamSynchronize(s));
+    SGX_HIP_CHECK(hipStreamSynchronize(s));                          // the ONE read-back of a plan build (40 bytes)
     if (host.n_tasks > 0x7FFFFFFFu) return SGX_ERR_SHAPE;
+    p->nnz = host.nnz;
+    const int long_threshold = p->long_threshold = host.long_threshold;
+    const int chunk = p->chunk = host.chunk;
+    const int steps_max = long_threshold / 8 + 1, n_buckets = steps_max + 1;
     p->n_long = (int)host.n_long;
     p->n_tasks = (int)host.n_tasks;
     p->natural_utilization = host.spent > 0 ? (float)((double)host.useful / (double)host.spent) : 1.0f;
+    bool launched_after_readback = false;
 
     if (p->n_long > 0) {
         const size_t nl = (size_t)p->n_long, nt = (size_t)p->n_tasks;
@@ -359,6 +372,7 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
         p->task_row = p->long_first + nl + 1;
         p->task_e0 = p->task_row + nt;
         p->task_e1 = p->task_e0 + nt;
+        launched_after_readback = true;
         hipLaunchKernelGGL(plan_scan_kernel, dim3(2), dim3(kMaxBlocks), 0, s, block_long, n_blocks, (int64_t)n_blocks, (int32_t *)nullptr);
         SGX_LAUNCH_CHECK();
         hipLaunchKernelGGL(plan_fill_long_kernel, dim3(n_blocks), dim3(kThreads), 0, s, rowPtr, n_rows, rows_per_block, long_threshold,
@@ -372,8 +386,7 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     // Would packing 8 consecutive rows per wavefront keep the lane groups busy?  A group needs ceil(deg / 8) steps, the
     // wavefront runs for the largest of its 8 rows: natural_utilization.  Below kReorderBelow the short rows are
     // scheduled in degree order instead.
-    float reorder_below = kReorderBelow;
-    if (const char *f = getenv("SGX_PLAN_REORDER_BELOW")) reorder_below = (float)atof(f);      // tuning override
+    const float reorder_below = tune.plan_reorder_below >= 0.0f ? tune.plan_reorder_below : kReorderBelow;      // (tuning override)
     Scratch order_mem;
     order_mem.s = s;
     if (p->natural_utilization < reorder_below && n_rows - p->n_long > 0) {
@@ -382,6 +395,7 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
         int32_t *counts = (int32_t *)order_mem.p, *bucket_base = counts + n_counts;
         SGX_HIP_CHECK(hipMalloc(&p->row_order, sizeof(int32_t) * (size_t)(n_rows - p->n_long)));
         p->n_ordered = n_rows - p->n_long;
+        launched_after_readback = true;
         const size_t lds = sizeof(int) * (size_t)n_buckets;
         hipLaunchKernelGGL(plan_hist_kernel, dim3(n_blocks), dim3(kThreads), lds, s, rowPtr, n_rows, rows_per_block, long_threshold,
                            steps_max, counts);
@@ -395,6 +409,10 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
                            steps_max, counts, bucket_base, p->row_order);
         SGX_LAUNCH_CHECK();
     }
+    // A plan is used from any stream (the partitioned layer launches on side streams): its arrays must be complete when
+    // this returns, not merely ordered on `stream`.  Only a plan with long rows or a degree order has kernels behind the
+    // read-back; the common plan (uniform graph, mini-batch) returned complete at the read-back's synchronisation.
+    if (launched_after_readback) SGX_HIP_CHECK(hipStreamSynchronize(s));
     guard.p = nullptr;
     *out = p;
     return SGX_OK;

@@ -19,6 +19,22 @@
 
 typedef _Float16 f16;
 
+// Tuning / test overrides: the SGX_* environment variables, read ONCE per process -- not per call: a getenv
+// walks the whole environment, and half a dozen of them per layer were a measurable share of a 20-microsecond layer
+// (Cora, MUTAG).  Sizing a scratch and launching on it therefore see the same settings.  A process that changes a
+// variable afterwards (tests and probes that compare two forms in one process) calls sgx_reload_env().
+struct sgx_tuning {
+    bool gat_one_pass, gat_no_fused_scores, gat_no_scan;
+    bool xw_no_wlds, xw_no_stationary_f32, xw_sparse_no_lds, xw_short_tiles, xw_no_lds;
+    bool xtg_scalar, xtg_wave_tiles;
+    int spmm_cpl;                 // 0 = unset
+    int plan_long_threshold;      // 0 = unset
+    int plan_chunk;               // 0 = unset
+    float plan_reorder_below;     // < 0 = unset
+    int plan_seg;                 // mid-degree rows cut into segments of this many edges (0 = default, < 0 = off)
+};
+const sgx_tuning &sgx_tune();     // util_kernels.hip
+
 static inline size_t sgx_elem_size(int dtype) { return dtype == SGX_F16 ? 2 : 4; }
 static inline size_t sgx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int sgx_next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }

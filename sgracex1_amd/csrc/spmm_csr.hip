@@ -433,7 +433,7 @@ int launch_lpr(const LaunchArgs &a, int slots, int cpl)
 // 2.52 vs 2.18 ms at 25; sparse X.W 0.98 vs 0.86 ms); CPL = 4 never wins.
 int choose_cpl(const sgx_plan *plan, int slots)
 {
-    if (const char *f = getenv("SGX_SPMM_CPL")) return atoi(f);          // tuning override (read per call: tools/cpl_probe.py flips it)
+    if (sgx_tune().spmm_cpl) return sgx_tune().spmm_cpl;                // tuning override (tools/cpl_probe.py)
     if (!plan || plan->n_rows <= 0 || slots < 2) return 1;
     const double avg = (double)plan->nnz / (double)plan->n_rows;
     return avg < kShortRowDegree ? 2 : 1;

@@ -271,3 +271,41 @@ extern "C" int sgx_plan_reordered(const sgx_plan *plan) { return plan && plan->r
 
 extern "C" int sgx_plan_long_rows(const sgx_plan *plan) { return plan ? plan->n_long : 0; }
 extern "C" int sgx_plan_long_threshold(const sgx_plan *plan) { return plan ? plan->long_threshold : 0; }
+
+// ---- tuning overrides: the environment, read once (sgx_internal.h) -----------------------------------------------------
+namespace {
+sgx_tuning g_tuning;
+bool g_tuning_loaded = false;
+void load_tuning()
+{
+    sgx_tuning t{};
+    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
+    t.gat_one_pass = flag("SGX_GAT_ONE_PASS");
+    t.gat_no_fused_scores = flag("SGX_GAT_NO_FUSED_SCORES");
+    t.gat_no_scan = flag("SGX_GAT_NO_SCAN");
+    t.xw_no_wlds = flag("SGX_XW_NO_WLDS");
+    t.xw_no_stationary_f32 = flag("SGX_XW_NO_STATIONARY_F32");
+    t.xw_sparse_no_lds = flag("SGX_XW_SPARSE_NO_LDS");
+    t.xw_short_tiles = flag("SGX_XW_SHORT_TILES");
+    t.xw_no_lds = flag("SGX_XW_NO_LDS");
+    t.xtg_scalar = flag("SGX_XTG_SCALAR");
+    t.xtg_wave_tiles = flag("SGX_XTG_WAVE_TILES");
+    t.spmm_cpl = num("SGX_SPMM_CPL");
+    t.plan_long_threshold = num("SGX_PLAN_LONG_THRESHOLD");
+    t.plan_chunk = num("SGX_PLAN_CHUNK");
+    const char *rb = getenv("SGX_PLAN_REORDER_BELOW");
+    t.plan_reorder_below = rb ? (float)atof(rb) : -1.0f;
+    t.plan_seg = num("SGX_PLAN_SEG");
+    g_tuning = t;
+    g_tuning_loaded = true;
+}
+}  // namespace
+
+const sgx_tuning &sgx_tune()
+{
+    if (!g_tuning_loaded) load_tuning();
+    return g_tuning;
+}
+
+extern "C" void sgx_reload_env(void) { load_tuning(); }

@@ -357,9 +357,9 @@ extern "C" int sgx_xt_g(int dtype_x, int n_rows, int M, int P, const void *X, in
     // 16-byte loads (8 bytes of halves) where the rows are dword-aligned and the tables fit 32-bit offsets
     const size_t es = dtype_x == SGX_F16 ? 2 : 4;
     // (a 16- or 8-byte buffer load wants dword alignment, no more: rows of 602 floats qualify)
-    const bool vec = !getenv("SGX_XTG_SCALAR") && ((uintptr_t)X % 4 == 0) && ((ldx * es) % 4 == 0) && ((uintptr_t)G % 4 == 0) &&
+    const bool vec = !sgx_tune().xtg_scalar && ((uintptr_t)X % 4 == 0) && ((ldx * es) % 4 == 0) && ((uintptr_t)G % 4 == 0) &&
                      (unsigned long long)n_rows * ldx * es < 0xFFF00000ull && (unsigned long long)n_rows * ldg * 4ull < 0xFFF00000ull;
-    if (vec && n_rows >= 16384 && !getenv("SGX_XTG_WAVE_TILES")) {
+    if (vec && n_rows >= 16384 && !sgx_tune().xtg_wave_tiles) {
         // enough rows to fill the device with workgroup tiles: the arrangement of the 8 sub-tiles with the fewest tiles
         const int mt = g.m_pad / kTile, pt = g.p_pad / kTile;
         const int best_wm = g.wm;

@@ -618,7 +618,7 @@ int launch_stationary_f32(int n_rows, int M, int P, int nt_total, const void *X,
 int try_stationary_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                        int xa, int wa, int ha, hipStream_t s, sgx_epilogue ep, int relu)
 {
-    if (M > 128 || n_rows < 8192 || getenv("SGX_XW_NO_STATIONARY_F32")) return SGX_ERR_UNSUPPORTED;      // (tuning / test override)
+    if (M > 128 || n_rows < 8192 || sgx_tune().xw_no_stationary_f32) return SGX_ERR_UNSUPPORTED;      // (tuning / test override)
     // the workgroup's 4 wavefronts take the column groups of the same row tile when there are 4 of them (X from L1 then)
     const int nt_total = (int)((ldh + 15) / 16);               // pad columns P..ldh-1 are produced (as zeros) too
     const int kb = (M + 15) / 16;
@@ -712,8 +712,7 @@ int sgx_xw_dense_ep(int dtype, int acc_mode, int spmm_block, int n_rows, int M_f
         rc = try_stationary_f32(n_rows, M_fea, P, X, ldx, Wt, ldw, H, ldh, xa, wa, ha, s, ep, relu);
         if (rc != SGX_ERR_UNSUPPORTED) return rc;
     }
-    static const bool short_tiles = getenv("SGX_XW_SHORT_TILES") != nullptr;      // tuning override, read once
-    static const bool no_lds = getenv("SGX_XW_NO_LDS") != nullptr;
+    const bool short_tiles = sgx_tune().xw_short_tiles, no_lds = sgx_tune().xw_no_lds;      // tuning overrides
     const bool tall = n_rows >= 32768 && !short_tiles;
     if (dtype == SGX_F16 && tall && !no_lds && M_fea > 128) {
         // all of W^T in LDS, X streamed through a register ring (xw_dense_wlds.hip): 602 -> 128 on 233 K rows

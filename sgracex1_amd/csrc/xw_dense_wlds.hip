@@ -275,7 +275,7 @@ int launch_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void
 int sgx_xw_dense_wlds(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                       int relu, hipStream_t stream)
 {
-    if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning override, read per call (tools/xw_dense_long_k_probe.py flips it)
+    if (sgx_tune().xw_no_wlds) return SGX_ERR_UNSUPPORTED;             // tuning override (tools/xw_dense_long_k_probe.py)
     if (M <= 128 || n_rows < 32768) return SGX_ERR_UNSUPPORTED;
     // X through 32-bit buffer offsets, 4-byte aligned rows (a 16-byte buffer load wants dword alignment)
     if ((uint64_t)n_rows * (uint64_t)ldx * 2ull >= 0xFFF00000ull || (ldx & 1) || ((uintptr_t)X & 3)) return SGX_ERR_UNSUPPORTED;
@@ -457,7 +457,7 @@ int launch_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const 
 int sgx_xw_dense_wlds_f32(int n_rows, int M, int P, const void *X, int64_t ldx, const void *Wt, int64_t ldw, void *H, int64_t ldh,
                           int h_aligned, sgx_epilogue ep, int relu, hipStream_t stream)
 {
-    if (getenv("SGX_XW_NO_WLDS")) return SGX_ERR_UNSUPPORTED;          // tuning / test override, read per call
+    if (sgx_tune().xw_no_wlds) return SGX_ERR_UNSUPPORTED;             // tuning / test override
     const int cols = (int)ldh;                                          // pad columns are produced (as zeros) too
     // wide outputs only: with few column tiles the register-stationary kernel reads X once as well; more than 256 columns
     // go in blocks of 256 (X re-read per block: 602 columns of the backward's g . W^T = 3 passes instead of the 10 of the

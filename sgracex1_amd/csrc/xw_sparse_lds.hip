@@ -394,7 +394,7 @@ int choose_lpr(int dtype, int m_fea, int n_feat)
 // and to at most 4 slices (the CSR of X is read once per slice, the re-reads out of L2).
 bool sgx_xw_sparse_lds_applicable(int dtype, int n_rows, int m_fea, int n_feat, int64_t ldh, const sgx_plan *plan)
 {
-    if (getenv("SGX_XW_SPARSE_NO_LDS")) return false;      // tuning override, read per call (tools/xw_sparse_probe.py flips it)
+    if (sgx_tune().xw_sparse_no_lds) return false;         // tuning override (tools/xw_sparse_probe.py)
     if (!plan || plan->n_tasks > 0 || plan->nnz < ((int64_t)1 << 20) || plan->nnz >= ((int64_t)1 << 30) || n_rows < 4096)
         return false;                                 // (32-bit buffer offsets into columnIndex: nnz x 4 bytes below 4 GiB)
     if ((unsigned long long)n_rows * (unsigned long long)ldh * (dtype == SGX_F16 ? 2ull : 4ull) >= 0xFFF00000ull)

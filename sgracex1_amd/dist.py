@@ -113,7 +113,6 @@ class HaloPlan:
     recv_counts: List[int]            # rows received from each owner
     n_own: int
     send_rows32: Optional[torch.Tensor] = None    # the same ids as int32 (what the pack kernel reads)
-    any_dead_rows: Optional[bool] = None          # GAT: does ANY rank hold a row without a live edge (decided once)
 
     @property
     def n_table(self):
@@ -154,6 +153,29 @@ def build_halo_plan(col_global: torch.Tensor, bounds: List[int], rank: int, grou
     send_rows = (req_in - lo).contiguous()
     return HaloPlan(bounds, rank, col_compact.to(torch.int32), send_rows, send_counts, recv_counts, hi - lo,
                     send_rows32=send_rows.to(torch.int32))
+
+
+def any_rank_has_dead_rows(adj_local, group=None, device=None):
+    """GAT: does ANY rank hold a row without a live edge?  That depends on the adjacency VALUES (`val > 0`, e.g. what a
+    quantiser left of them), not on the structure the halo plan describes, so the answer is kept on the adjacency object
+    (with the version counter of its value tensor: an in-place change asks again), never on the plan -- a plan reused
+    with another adjacency would otherwise keep a stale answer and rows without a neighbour would silently get 0 instead
+    of the all-node mean (SG.py:638-641).  Every rank takes its branch from the ALL-REDUCED flag only; the ranks call
+    this with adjacency objects made in lockstep (as every collective here assumes), so they hit or miss together."""
+    val = getattr(adj_local, "val", None)
+    version = getattr(val, "_version", None)
+    key = ("any_dead_rows", id(group))
+    store = getattr(adj_local, "__dict__", None)
+    hit = store.get("_sgx_dist_cache", {}).get(key) if store is not None else None
+    if hit is not None and hit[0] == version:
+        return hit[1]
+    local = bool(getattr(adj_local, "has_dead_rows", True))          # an adjacency that cannot say: assume so
+    dev = device if device is not None else (val.device if isinstance(val, torch.Tensor) else "cpu")
+    flag = torch.tensor([float(local)], dtype=torch.float32, device=dev)
+    answer = bool(all_reduce_sum(flag, group=group).item() > 0)
+    if store is not None:
+        store.setdefault("_sgx_dist_cache", {})[key] = (version, answer)
+    return answer
 
 
 @dataclass
@@ -247,7 +269,8 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     nodes, the row receives the mean of all rows of Wh (SG.py:638-641).  One rank sees only its own and its halo
     rows, so the column sums of every rank's rows are all-reduced (P floats) and the mean is handed to the
     aggregate -- the same result as on one GPU.  fill_dead_rows: None = do this when any rank holds such a row
-    (decided once per plan with one all-reduce of a flag), True / False = always / never (then such rows give 0)."""
+    (decided once per ADJACENCY with one all-reduce of a flag, any_rank_has_dead_rows), True / False = always / never
+    (then such rows give 0)."""
     if aggregate_first and attention is not None:
         raise ValueError("the edge softmax needs Wh: no aggregate-first order for GAT")
     h_local, relu, finish = _stages(backend, fea_local, Wt, relu, aggregate_first)
@@ -259,11 +282,7 @@ def layer_halo(backend: Backend, adj_compact, fea_local, Wt, relu, plan: HaloPla
     all_to_all_rows(table[plan.n_own:], packed, plan.recv_counts, plan.send_counts, group=group)
     if attention is not None:
         if fill_dead_rows is None:
-            if plan.any_dead_rows is None:
-                local = bool(getattr(adj_compact, "has_dead_rows", True))      # without the attribute: assume so
-                flag = torch.tensor([float(local)], dtype=torch.float32, device=h_local.device)
-                plan.any_dead_rows = bool(all_reduce_sum(flag, group=group).item() > 0)
-            fill_dead_rows = plan.any_dead_rows
+            fill_dead_rows = any_rank_has_dead_rows(adj_compact, group=group, device=h_local.device)
         if not fill_dead_rows:
             return backend.gat(adj_compact, table, attention, alpha, relu)
         if backend.col_sums is None:

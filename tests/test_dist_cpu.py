@@ -150,9 +150,25 @@ def _worker(rank, world, port, tmp, balance_nnz):
         dead_all = pos.sum(1) == 0
         assert bool(dead_all[lo:hi].any()) and torch.allclose(a_all[dead_all], torch.full_like(a_all[dead_all], 1.0 / n))
         want_gat = torch.clamp(a_all @ H_all, min=0)
-        d4 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan, attention=att)
+        adj_gat = LocalCsr(lrp, plan.col_compact, lva, plan.n_table)
+        d4 = D.layer_halo(backend, adj_gat, Xl, Wt, True, plan, attention=att)
         np.testing.assert_allclose(d4.numpy(), want_gat[lo:hi].numpy(), rtol=1e-4, atol=1e-5)
-        assert plan.any_dead_rows is True                       # decided once, by all ranks together
+        assert D.any_rank_has_dead_rows(adj_gat) is True        # decided once per adjacency, by all ranks together
+        # the same PLAN with an adjacency whose rows all keep a live edge (every stored value positive, a self loop added
+        # to the empty rows): the decision follows the adjacency's values -- a flag kept on the plan would be stale here
+        live_val = lva.abs() + 0.5
+        adj_live = LocalCsr(lrp, plan.col_compact, live_val, plan.n_table)
+        adj_live.has_dead_rows = bool(((lrp[1:] - lrp[:-1]) == 0).any())
+        expect_any = torch.tensor([float(adj_live.has_dead_rows)])
+        dist.all_reduce(expect_any)
+        assert D.any_rank_has_dead_rows(adj_live) is bool(expect_any.item() > 0)
+        # an in-place change of the values asks again (all ranks together)
+        adj_flip = LocalCsr(lrp, plan.col_compact, lva.clone(), plan.n_table)
+        adj_flip.has_dead_rows = False
+        assert D.any_rank_has_dead_rows(adj_flip) is False
+        adj_flip.val.mul_(1.0)
+        adj_flip.has_dead_rows = True
+        assert D.any_rank_has_dead_rows(adj_flip) is True
         # the cheaper sparse answer stays available: such rows give 0
         d5 = D.layer_halo(backend, LocalCsr(lrp, plan.col_compact, lva, plan.n_table), Xl, Wt, True, plan, attention=att,
                           fill_dead_rows=False)

@@ -25,12 +25,9 @@ def test_xt_g_matches_fp64(xdtype, n, M, P):
     again = ops.xt_g(X, G)
     assert torch.equal(got, again)                               # slab sums are order-fixed
     # the 16-byte-load kernel (aligned rows) and the scalar one it stands beside: every output sums its rows in the same order
-    import os
-    os.environ["SGX_XTG_SCALAR"] = "1"
-    try:
+    from sgracex1_amd import _lib
+    with _lib.tuning(SGX_XTG_SCALAR="1"):
         scalar = ops.xt_g(X, G)
-    finally:
-        del os.environ["SGX_XTG_SCALAR"]
     assert torch.equal(got, scalar)
 
 

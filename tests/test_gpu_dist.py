@@ -74,9 +74,10 @@ def _worker(rank, world, port, tmp):
         want2, _, S2 = ops.layer_forward(A2, X, Wt, relu=True, gat_attention=att, want_edge_outputs=True)
         rp2, ci2, va2 = D.slice_rows(A2.rowptr, A2.col, A2.val, lo, hi)
         A2_loc = ops.Csr(rp2, plan.col_compact, va2, plan.n_table)
-        plan.any_dead_rows = None
+        # the SAME plan with another adjacency: the dead-row decision belongs to the adjacency's values, not to the plan
+        # (the adjacency of d4 above has no such row and decided "no fill")
         d5 = D.layer_halo(backend, A2_loc, X[lo:hi].contiguous(), Wt, True, plan, attention=att)
-        assert plan.any_dead_rows is True and bool(dead[lo:hi].any())
+        assert D.any_rank_has_dead_rows(A2_loc) is True and bool(dead[lo:hi].any())
         assert torch.allclose(d5.float(), want2[lo:hi].float(), rtol=2e-3, atol=2e-3)
         assert torch.equal(d5[~dead[lo:hi]], want2[lo:hi][~dead[lo:hi]])            # live rows: the same bits as before
         H_all = ops.xw_dense(X, Wt).float()
@@ -127,6 +128,27 @@ def test_bench_multi_rank_path_rehearsal(extra, expect):
     assert x["ms_alone_per_layer"] > 0 and x["rows_received_per_rank_per_layer"] > 0
     assert x["bytes_received_per_rank_per_layer"] == x["rows_received_per_rank_per_layer"] * rec["config"]["hidden"] * 2
     assert 0 < x["max_bytes_per_link_per_layer"] <= x["bytes_received_per_rank_per_layer"] * 2
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run in front, the shape of the driver's N = 1 command): the
+    parent starts the two ranks as a child process and relays rank 0's line -- ONE line on stdout, the same schema."""
+    import json
+    env = dict(os.environ, SGX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory() as tmp:
+        env["SGX_BENCH_PARENT_REPORT"] = os.path.join(tmp, "parent.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                              "--workload", "small"], env=env, capture_output=True, text=True, timeout=900)
+        rep = json.load(open(env["SGX_BENCH_PARENT_REPORT"]))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["backend"] == "gloo" and rec["value"] > 0
+    assert len(rec["devices"]) == 2 and "exchange" in rec and "exchange_allgather" in rec and "roofline" in rec
+    assert rep["torch_imported"] is False and rep["rc"] == 0 and rep["cmd"][1:3] == ["-m", "torch.distributed.run"]
 
 
 def test_bench_falls_back_to_the_one_pass_halo_exchange():

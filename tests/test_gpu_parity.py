@@ -617,8 +617,7 @@ def test_xw_dense_weights_in_lds(M, P):
     two column blocks, 2 / 4 / 8 column tiles, K a multiple of 32 or not, odd K (2-byte aligned rows: stays with the
     tile kernel), a ragged last row tile.  Rows of NaN / Inf stay in their rows: a row's last k-step reads into the
     next row and is masked."""
-    import os
-    from sgracex1_amd import ops
+    from sgracex1_amd import _lib, ops
     g = torch.Generator(device="cuda")
     g.manual_seed(M * 7 + P)
     n = 33_000 + 13
@@ -629,11 +628,8 @@ def test_xw_dense_weights_in_lds(M, P):
     X[bad + 0, 0] = float("inf")
     got = ops.xw_dense(X, Wt)
     act = ops.xw_dense(X, Wt, relu=True)
-    os.environ["SGX_XW_NO_WLDS"] = "1"
-    try:
+    with _lib.tuning(SGX_XW_NO_WLDS="1"):
         tile = ops.xw_dense(X, Wt)
-    finally:
-        del os.environ["SGX_XW_NO_WLDS"]
     ok = torch.ones(n, dtype=torch.bool, device="cuda")
     ok[bad] = False
     assert torch.equal(got[ok], tile[ok]) and torch.isfinite(got[ok].float()).all()
@@ -725,8 +721,7 @@ def test_xw_dense_fp32_weights_in_registers(M, P):
     """fp32 X.W with K <= 128 on 8 K rows and more: the weights-stationary kernel (W fragments in registers, X streamed)
     against the tile kernel it replaces -- same sums in the same order, so the same bits -- and against torch in fp32;
     with the ReLU on the stores; ragged last tile, pad columns zero."""
-    import os
-    from sgracex1_amd import ops
+    from sgracex1_amd import _lib, ops
     g = torch.Generator(device="cuda")
     g.manual_seed(M * 13 + P)
     n = 20_000 + 11
@@ -734,11 +729,8 @@ def test_xw_dense_fp32_weights_in_registers(M, P):
     Wt = (torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5
     got = ops.xw_dense(X, Wt)
     act = ops.xw_dense(X, Wt, relu=True)
-    os.environ["SGX_XW_NO_STATIONARY_F32"] = "1"
-    try:
+    with _lib.tuning(SGX_XW_NO_STATIONARY_F32="1"):
         tile = ops.xw_dense(X, Wt)
-    finally:
-        del os.environ["SGX_XW_NO_STATIONARY_F32"]
     assert torch.equal(got, tile)
     torch.testing.assert_close(got, X @ Wt.t(), rtol=1e-5, atol=1e-5)
     assert torch.equal(act, torch.where(got > 0, got, torch.zeros_like(got)))
@@ -751,8 +743,7 @@ def test_xw_dense_fp32_weights_in_lds(M, P):
     """fp32 X.W, K <= 128, more than 64 output columns, 32 K rows and more: all of W^T in LDS and every wavefront on all
     column tiles of its row tiles (xw_dense_wlds_f32_kernel) against the tile kernel -- the same sums in the same order,
     the same bits -- against torch, with the ReLU on the stores, rows of NaN staying in their rows."""
-    import os
-    from sgracex1_amd import ops
+    from sgracex1_amd import _lib, ops
     g = torch.Generator(device="cuda")
     g.manual_seed(M * 17 + P)
     n = 40_000 + 5
@@ -762,12 +753,8 @@ def test_xw_dense_fp32_weights_in_lds(M, P):
     X[bad] = float("nan")
     got = ops.xw_dense(X, Wt)
     act = ops.xw_dense(X, Wt, relu=True)
-    os.environ["SGX_XW_NO_WLDS"] = "1"
-    os.environ["SGX_XW_NO_STATIONARY_F32"] = "1"
-    try:
+    with _lib.tuning(SGX_XW_NO_WLDS="1", SGX_XW_NO_STATIONARY_F32="1"):
         tile = ops.xw_dense(X, Wt)
-    finally:
-        del os.environ["SGX_XW_NO_WLDS"], os.environ["SGX_XW_NO_STATIONARY_F32"]
     ok = torch.ones(n, dtype=torch.bool, device="cuda")
     ok[bad] = False
     assert torch.equal(got[ok], tile[ok]) and torch.isnan(got[~ok]).all()
@@ -786,8 +773,7 @@ def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
     wide heads as a partial per 64-column group, added by a small kernel in the scores kernel's tree order) instead of a
     pass over H of its own.  Same eight-term chains and the same tree, so the layer equals -- bit for bit -- the same layer
     with SGX_GAT_NO_FUSED_SCORES and the composition xw_dense + gat_aggregate; E and S too."""
-    import os
-    from sgracex1_amd import graphs, ops
+    from sgracex1_amd import _lib, graphs, ops
     n = 24_000 + 7
     A = (graphs.rmat_graph_n if gen_name == "rmat" else graphs.uniform_graph)(n, 400_000, seed=M + P)
     g = torch.Generator(device="cuda")
@@ -796,11 +782,8 @@ def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
     Wt = ((torch.rand((P, M), generator=g, device="cuda") * 2 - 1) / M ** 0.5).half()
     att = ((torch.rand(2 * P, generator=g, device="cuda") * 2 - 1) * 0.3).half()
     fused, E, S = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
-    os.environ["SGX_GAT_NO_FUSED_SCORES"] = "1"
-    try:
+    with _lib.tuning(SGX_GAT_NO_FUSED_SCORES="1"):
         plain, E0, S0 = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
-    finally:
-        del os.environ["SGX_GAT_NO_FUSED_SCORES"]
     assert torch.equal(fused, plain) and torch.equal(E, E0) and torch.equal(S, S0)
     Wh = ops.xw_dense(X, Wt)
     composed = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from sgracex1_amd import graphs, ops  # noqa: E402
+from sgracex1_amd import _lib
 from sgracex1_amd.hipevents import Event  # noqa: E402
 
 
@@ -32,8 +33,10 @@ def probe(name, A, table, out):
     rec = {"case": name, "rows": A.n_rows, "nnz": A.nnz, "avg_deg": round(A.nnz / A.n_rows, 2), "P": table.shape[1]}
     for cpl in (1, 2, 4):
         os.environ["SGX_SPMM_CPL"] = str(cpl)
+        _lib.lib.sgx_reload_env()      # the library reads its overrides once; have it read them again
         rec[f"ms_cpl{cpl}"] = round(timed(lambda: ops.spmm(A, table, relu=False, out=out)), 4)
     del os.environ["SGX_SPMM_CPL"]
+    _lib.lib.sgx_reload_env()      # the library reads its overrides once; have it read them again
     rec["ms_policy"] = round(timed(lambda: ops.spmm(A, table, relu=False, out=out)), 4)
     print(json.dumps(rec), flush=True)
 
