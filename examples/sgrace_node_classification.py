@@ -7,7 +7,10 @@ downloaded by torch_geometric and are not available offline.
     python examples/sgrace_node_classification.py [--attention] [--qbits 8] [--epochs 60] [--acc 0]
 
 --attention  GAT edge softmax instead of the GCN aggregate (config.compute_attention)
---qbits B    run the layers with the quantised arithmetic of the SGRACE bitstream (config.fake_quantization)
+--qbits B    run the layers with the quantised arithmetic of the SGRACE bitstream (config.fake_quantization and
+             config.hardware_quantize, as the reference's board configs set them: integer operands on the int8 matrix
+             cores for the dense-feature layer when it is wider than 128 columns -- --hidden 256 makes layer 2 such a layer)
+--emulate    with --qbits: config.fake_quantization only (the fp32 emulation of the grid everywhere)
 --acc 0      the reference's dense torch emulation instead of the kernels (small graphs only)
 """
 import argparse
@@ -37,11 +40,12 @@ def planted_partition(n, classes, f_in, p_in, p_out, seed, device):
     return x.to(device), edge_index.to(device), y.to(device)
 
 
-def run(attention=False, qbits=32, epochs=60, acc=1, n=3000, hidden=16, seed=1, verbose=True):
+def run(attention=False, qbits=32, epochs=60, acc=1, n=3000, hidden=16, seed=1, verbose=True, emulate=False):
     from sgracex1_amd import config, sgrace
     config.acc = acc
     config.compute_attention = int(attention)
     config.fake_quantization = int(qbits != 32)
+    config.hardware_quantize = int(qbits != 32 and not emulate)
     config.w_qbits = qbits
     config.float_type = np.float32
     device = torch.device("cuda" if acc == 1 else "cpu")
@@ -83,5 +87,8 @@ if __name__ == "__main__":
     ap.add_argument("--qbits", type=int, default=32, choices=[32, 8, 4, 2, 1])
     ap.add_argument("--epochs", type=int, default=60)
     ap.add_argument("--acc", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--hidden", type=int, default=16)
+    ap.add_argument("--nodes", type=int, default=3000)
+    ap.add_argument("--emulate", action="store_true")
     a = ap.parse_args()
-    run(a.attention, a.qbits, a.epochs, a.acc)
+    run(a.attention, a.qbits, a.epochs, a.acc, n=a.nodes, hidden=a.hidden, emulate=a.emulate)

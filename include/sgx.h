@@ -94,7 +94,8 @@ int sgx_plan_long_threshold(const sgx_plan *plan);
 float sgx_plan_natural_utilization(const sgx_plan *plan);
 int sgx_plan_reordered(const sgx_plan *plan);
 /* One of the plan's device arrays copied to dst (device, int32, `capacity` entries) for inspection and tests:
- * which = 0 long_row, 1 long_first, 2 task_row, 3 task_e0, 4 task_e1, 5 row_order.  Returns the array's length
+ * which = 0 long_row, 1 long_first, 2 task_row, 3 task_e0, 4 task_e1, 5 row_order, 6 win_order (the rows of every 64-row
+ * window by length, one byte per row, four to an int32; built for matrices of 2^20 entries and more without long rows).  Returns the array's length
  * (dst NULL: the length only) or a negative sgx error. */
 int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream);
 
@@ -112,6 +113,11 @@ int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t c
                                   exactly in int32 instead of in fp32, X read as 1 byte per element.  Equal to the fp32
                                   form whenever that form's sums are exact (|sum of code products| < 2^24), to fp32
                                   rounding otherwise.  Ignored (fp32 form) where it does not apply.              */
+#define SGX_QUANT_INT8_AUTO 4  /* flags: the integer operands where they are the faster form -- M_fea > 128, i.e. where
+                                  the fp32 product no longer has its weights-stationary kernels (those hold W for
+                                  K <= 128: at K = 128 the two forms tie, at Reddit's 602 the integer form takes half
+                                  the time, X being read as bytes).  What `config.hardware_quantize = 1` selects in
+                                  the SGRACE library's layers (SG.py:570-616: the bitstream's own quantiser).       */
 typedef struct sgx_quant {
     int32_t qbits;              /* config.w_qbits: 8, 4, 2 or 1                                       */
     int32_t scale_fea;          /* register scale_fea                                                 */

@@ -19,6 +19,7 @@ SGX_F16, SGX_F32 = 0, 1
 SGX_ACC_F32, SGX_ACC_REF_HALF = 0, 1
 SGX_ORDER_REFERENCE, SGX_ORDER_AGGREGATE_FIRST = 0, 1      # sgx_layer_order
 SGX_QUANT_INT8 = 2                                          # sgx_quant.flags: integer operands on the int8 matrix cores
+SGX_QUANT_INT8_AUTO = 4                                     # ... where they are the faster form (M_fea > 128)
 
 # every symbol include/sgx.h declares (tests/test_abi.py checks header and library against this)
 SYMBOLS = [

@@ -37,7 +37,9 @@ _FLAGS = {
     # -- quantised bitstream (SG.py:570-667, :1645-1848; sgracex1_amd/quant.py) ------------------------
     "fake_quantization": (0, "1 = layers use the quantised arithmetic of the SGRACE bitstream (fp32 tensors, "
                              "w_qbits in {8, 4, 2, 1}); read by init_SGRACE and FPYNQ_GAT"),
-    "hardware_quantize": (0, "the bitstream's own quantiser: same arithmetic here as fake_quantization"),
+    "hardware_quantize": (0, "the bitstream's own quantiser: the arithmetic of fake_quantization with X and W as integer codes "
+                             "on the int8 matrix cores where that is the faster form (dense features wider than 128 "
+                             "columns; exact int32 sums instead of fp32 ones)"),
     "w_qbits": (32, "operand bits of the quantised layer; 32 = not quantised"),
     # -- buffer capacities of the PYNQ allocation step (informational here) ----------------------
     "N_adj": (20480, "max nodes"), "M_adj": (20480, "max nodes"), "M_fea": (2048, "max input features"),

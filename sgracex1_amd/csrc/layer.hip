@@ -33,7 +33,11 @@ bool repitch_x(const sgx_layer_desc *d)
 // the int8 operand form applies to a dense X with codes of at most 8 bits and an output of at most 256 columns
 bool int8_form(const sgx_layer_desc *d)
 {
-    return d->quant && (d->quant->flags & SGX_QUANT_INT8) && d->gemm_mode == 1 && d->quant->qbits <= 8 && d->P_w <= 256;
+    if (!d->quant || d->gemm_mode != 1 || d->quant->qbits > 8 || d->P_w > 256) return false;
+    if (d->quant->flags & SGX_QUANT_INT8) return true;
+    // by shape: the fp32 form keeps W in registers / LDS for K <= 128 and is as fast there; beyond it runs the fp32 tile
+    // kernel at the fp32 matrix rate while the integer form reads X as bytes (profiles/r03_configs_c5_int8.jsonl)
+    return (d->quant->flags & SGX_QUANT_INT8_AUTO) && d->M_fea > 128;
 }
 
 Carve carve(const sgx_layer_desc *d)

@@ -296,6 +296,32 @@ __global__ __launch_bounds__(kThreads) void plan_scatter_kernel(const int32_t *_
     }
 }
 
+// win_order (sgx_internal.h): one wavefront per window of 64 rows, a bitonic network over the lanes on keys
+// (0xFFFFF - min(length, 0xFFFFF)) : lane -- ascending keys = longest first, ties in row order.
+__global__ __launch_bounds__(kThreads) void plan_window_order_kernel(const int32_t *__restrict__ rowptr, int n_rows, int64_t n_windows,
+                                                                     uint8_t *__restrict__ win_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (w >= n_windows) return;
+    const int64_t row = w * 64 + lane;
+    int len = row < n_rows ? rowptr[row + 1] - rowptr[row] : 0;
+    len = len > 0xFFFFF ? 0xFFFFF : len;
+    unsigned key = ((unsigned)(0xFFFFF - len) << 6) | (unsigned)lane;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned other = (unsigned)__shfl_xor((int)key, j);
+            const bool up = (lane & k) == 0 || k == 64;
+            const bool lower = (lane & j) == 0;
+            const unsigned lo = key < other ? key : other, hi = key < other ? other : key;
+            key = (lower == up) ? lo : hi;
+        }
+    }
+    win_order[w * 64 + lane] = (uint8_t)(key & 63u);
+}
+
 // The builder's own scratch comes from the stream-ordered pool and goes back to it on the same stream (on every way
 // out): no synchronisation is needed to free it after the kernels that read it, and a builder called per mini-batch
 // does not pay hipMalloc / hipFree each time.
@@ -328,7 +354,9 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     p->n_long = p->n_tasks = 0;
     p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
     p->row_order = nullptr;
+    p->win_order = nullptr;
     p->n_ordered = 0;
+    p->n_multi = -1;
     p->natural_utilization = 1.0f;
     resolve_cut(0, long_threshold_arg, chunk_arg, tune.plan_long_threshold, tune.plan_chunk, p->long_threshold, p->chunk);
     if (n_blocks == 0) {
@@ -408,6 +436,21 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
         hipLaunchKernelGGL(plan_scatter_kernel, dim3(n_blocks), dim3(kThreads), lds, s, rowPtr, n_rows, rows_per_block, long_threshold,
                            steps_max, counts, bucket_base, p->row_order);
         SGX_LAUNCH_CHECK();
+        // where the one-step rows begin in the order (bucket k = steps_max - steps, scanned: the start of bucket steps_max - 1);
+        // read with the synchronisation that ends the build anyway
+        int32_t start_one = 0;
+        SGX_HIP_CHECK(hipMemcpyAsync(&start_one, bucket_base + (steps_max - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        SGX_HIP_CHECK(hipStreamSynchronize(s));
+        p->n_multi = start_one;
+    }
+    // the window order of the sparse X.W stage's LDS form, for the matrices that form takes (xw_sparse_lds.hip)
+    if (p->n_tasks == 0 && p->nnz >= ((int64_t)1 << 20) && n_rows >= 4096) {
+        const int64_t n_windows = ((int64_t)n_rows + 63) / 64;
+        SGX_HIP_CHECK(hipMalloc(&p->win_order, (size_t)n_windows * 64));
+        launched_after_readback = true;
+        hipLaunchKernelGGL(plan_window_order_kernel, dim3((unsigned)((n_windows + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, s,
+                           rowPtr, n_rows, n_windows, p->win_order);
+        SGX_LAUNCH_CHECK();
     }
     // A plan is used from any stream (the partitioned layer launches on side streams): its arrays must be complete when
     // this returns, not merely ordered on `stream`.  Only a plan with long rows or a degree order has kernels behind the
@@ -429,11 +472,12 @@ extern "C" void sgx_plan_destroy(sgx_plan *plan)
     if (!plan) return;
     if (plan->long_row) (void)hipFree(plan->long_row);     // one blob, long_row is its base
     if (plan->row_order) (void)hipFree(plan->row_order);
+    if (plan->win_order) (void)hipFree(plan->win_order);
     delete plan;
 }
 
 // One of the plan's arrays copied (device to device) for inspection: 0 long_row, 1 long_first, 2 task_row, 3 task_e0,
-// 4 task_e1, 5 row_order.  Returns the array's length (dst == NULL: the length only) or a negative sgx error.
+// 4 task_e1, 5 row_order, 6 win_order (its bytes, four to an int32).  Returns the array's length (dst == NULL: the length only) or a negative sgx error.
 extern "C" int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream)
 {
     if (!plan) return SGX_ERR_NULL;
@@ -446,6 +490,10 @@ extern "C" int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst
     case 3: src = plan->task_e0; n = plan->n_tasks; break;
     case 4: src = plan->task_e1; n = plan->n_tasks; break;
     case 5: src = plan->row_order; n = plan->row_order ? plan->n_ordered : 0; break;
+    case 6:                      // win_order: bytes, four to an int32 (64 per window of 64 rows)
+        src = reinterpret_cast<const int32_t *>(plan->win_order);
+        n = plan->win_order ? ((int64_t)plan->n_rows + 63) / 64 * 16 : 0;
+        break;
     default: return SGX_ERR_UNSUPPORTED;
     }
     if (!dst || n == 0) return n;

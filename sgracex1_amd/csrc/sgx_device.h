@@ -50,6 +50,25 @@ template <> struct Fma<f16, 8> {
         }
     }
 };
+// acc[0:VEC] = a * raw + (+0): the first term of a sum -- the same value as Fma onto a register holding +0
+template <typename T, int VEC> struct FmaInit;
+template <> struct FmaInit<f16, 8> {
+    static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned pair = raw[i];
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(acc[2 * i]) : "v"(pair), "v"(a));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc[2 * i + 1]) : "v"(pair), "v"(a));
+        }
+    }
+};
+template <> struct FmaInit<float, 4> {
+    static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
+        union { u32x4 v; float f[4]; } u; u.v = raw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(a, u.f[i], 0.0f);
+    }
+};
 template <> struct Fma<float, 4> {
     static __device__ __forceinline__ void run(float *acc, float a, u32x4 raw) {
         union { u32x4 v; float f[4]; } u; u.v = raw;

@@ -27,11 +27,11 @@ struct sgx_tuning {
     bool gat_one_pass, gat_no_fused_scores, gat_no_scan;
     bool xw_no_wlds, xw_no_stationary_f32, xw_sparse_no_lds, xw_short_tiles, xw_no_lds;
     bool xtg_scalar, xtg_wave_tiles;
+    bool spmm_no_short_tail;      // the one-step tail of a degree order through the sblock path (as in round 2)
     int spmm_cpl;                 // 0 = unset
     int plan_long_threshold;      // 0 = unset
     int plan_chunk;               // 0 = unset
     float plan_reorder_below;     // < 0 = unset
-    int plan_seg;                 // mid-degree rows cut into segments of this many edges (0 = default, < 0 = off)
 };
 const sgx_tuning &sgx_tune();     // util_kernels.hip
 
@@ -60,6 +60,12 @@ struct sgx_plan {
     // bucketed by the number of 8-edge steps they need, longest first, ascending inside a bucket.
     int32_t *row_order;    // [n_ordered]
     int n_ordered;
+    int n_multi;           // the order's rows of two steps and more: row_order[0, n_multi); the rest hold at most 8 edges (-1: no order)
+    // The rows of every window of 64 consecutive rows by length, longest first (ties in row order): win_order[64 w + k] =
+    // the row (0..63, inside window w) of rank k.  What the LDS form of the sparse X.W stage deals to its sub-tiles
+    // (xw_sparse_lds.hip; round 2 sorted every window inside the kernel, 7 % of its instructions); built for the
+    // matrices that form can take (2^20 entries and more, no long rows), NULL otherwise.
+    uint8_t *win_order;    // [ceil(n_rows / 64) * 64]
     float natural_utilization;   // share of lane-group steps doing work when rows are packed in natural order
 };
 

@@ -192,13 +192,83 @@ __device__ __forceinline__ void store_row(T *__restrict__ drow, int col0, int n_
 }
 
 // ---------------------------------------------------------------------------------------
+// One-step rows, 64 per wavefront.  In a power-law graph most rows hold a handful of edges (R-MAT S-100M: 47 % of the
+// rows are their self loop, 80 % hold at most 8 edges) and their cost is not bytes but the chain row id -> row pointers
+// -> (column, value) -> gather -> store, a memory round trip per link, paid by a wavefront for 64 / LPR rows at a
+// time.  Here every link of the chain is ONE round trip for 64 rows: lane l reads the row id and the row pointers of
+// row l, the (column, value) pairs of all LPR iterations are requested back to back, then the lane groups take
+// 64 / LPR rows per iteration as in the sblock path -- the same fma chain per output element, hence the same bits.
+// The plan's degree order ends with these rows (row_order[n_multi, n_rows): at most 8 edges each).
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR>
+__device__ __forceinline__ void spmm_short_rows(
+    int64_t i0, int n_items, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+    const T *__restrict__ val, __amdgpu_buffer_rsrc_t rsrc, unsigned ld_bytes, T *__restrict__ D, int64_t ldd, int relu,
+    int vec_store, const int32_t *__restrict__ row_order, const float *__restrict__ acc_in, float *__restrict__ acc_out,
+    int64_t ld_acc, const sgx_epilogue &ep)
+{
+    static_assert(LPR >= 8, "a row's 8 edge slots are loaded by 8 lanes of its group");
+    constexpr int RPW = 64 / LPR, ITER = LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, grp = lane / LPR;
+    const int64_t idx = i0 + lane;
+    const bool valid = idx < n_items;
+    const int r = row_order[valid ? idx : (int64_t)n_items - 1];
+    const int e0 = rowptr[r];
+    const int deg = valid ? rowptr[r + 1] - e0 : 0;               // at most 8 (the plan's last buckets)
+    // the (column, value) pairs of all iterations; unconditional loads (a conditional load makes hipcc wait for it at
+    // the join): slots past the end of a row read entry 0 and are masked when they are used
+    unsigned c[ITER];
+    T a[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int s = it * RPW + grp;
+        const int se0 = __shfl(e0, s), sdeg = __shfl(deg, s);
+        const int e = sub < sdeg ? se0 + sub : 0;
+        c[it] = (unsigned)__builtin_nontemporal_load(col + e);
+        a[it] = __builtin_nontemporal_load(val + e);
+    }
+    const int col0 = sub * VEC;
+    const unsigned chunk_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int s = it * RPW + grp;
+        const int sdeg = __shfl(deg, s);
+        const int64_t rr = __shfl(r, s);
+        const bool live = __shfl((int)valid, s) != 0;
+        float acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+        if (acc_in && live) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (col0 + i < n_feat) acc[i] = acc_in[rr * ld_acc + col0 + i];
+        }
+        const float af = Elem<T>::to_f32(a[it]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned cc = (unsigned)__shfl((int)c[it], t, LPR);
+            const float aa = __shfl(af, t, LPR);
+            Gather<T, VEC>::run(acc, aa, rsrc, (t < sdeg && chunk_off != kOOB) ? cc * ld_bytes + chunk_off : kOOB);
+        }
+        if (live && acc_out) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                if (col0 + i < n_feat) acc_out[rr * ld_acc + col0 + i] = acc[i];
+        } else if (live && col0 < n_feat) {
+            store_row<T, VEC>(D + rr * ldd, col0, n_feat, acc, relu, vec_store != 0, ep);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // One launch, two kinds of workgroup.  Workgroups [0, split_blocks) run the split path: one
 // wavefront per (long row, 512-edge chunk), all 64/LPR lane groups on the same row, fp32 partial
 // rows.  The others run the sblock path: one group of LPR lanes per row, 64/LPR rows per
 // wavefront.  Putting both in one grid lets the heavy chunks start first and the short rows fill
 // in around them (on R-MAT the two paths as separate launches took 0.98 + 1.24 ms back to back).
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int CPL, bool BIG, int STYLE>
+template <typename T, int VEC, int LPR, int CPL, bool BIG, int STYLE, bool SHORT>
 __device__ __forceinline__ void spmm_body(
     int n_rows, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ H, unsigned h_bytes, unsigned ld_bytes,
@@ -206,7 +276,7 @@ __device__ __forceinline__ void spmm_body(
     const int32_t *__restrict__ row_order,
     int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
     float *__restrict__ partial, int ldp,
-    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc, sgx_epilogue ep)
+    const float *__restrict__ acc_in, float *__restrict__ acc_out, int64_t ld_acc, sgx_epilogue ep, int n_multi, int short_first)
 {
     constexpr int RPW = 64 / LPR;                 // rows per wavefront
     constexpr int LANE_COLS = CPL * VEC;          // columns per lane
@@ -246,9 +316,21 @@ __device__ __forceinline__ void spmm_body(
         return;
     }
 
+    if constexpr (SHORT && LPR >= 8 && CPL == 1 && !BIG) {
+        // ---- one-step rows: the tail of the degree order, 64 rows per wavefront (workgroups from short_first on) ----
+        if ((int)blockIdx.x >= short_first) {
+            const int64_t i0 = (int64_t)n_multi + ((int64_t)((int)blockIdx.x - short_first) * (kBlock / 64) + (threadIdx.x >> 6)) * 64;
+            if (i0 < n_rows)
+                spmm_short_rows<T, VEC, LPR>(i0, n_rows, n_feat, rowptr, col, val, rsrc, ld_bytes, D, ldd, relu, vec_store, row_order,
+                                             acc_in, acc_out, ld_acc, ep);
+            return;
+        }
+        n_rows = n_multi;                    // the sblock path below walks the rows of two steps and more
+    }
+    const int row_grid = (SHORT ? short_first : (int)gridDim.x) - split_blocks;
     // ---- sblock path ----
     const int64_t wave = (int64_t)(blockIdx.x - split_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)(gridDim.x - split_blocks) * (kBlock / 64);
+    const int64_t n_waves = (int64_t)row_grid * (kBlock / 64);
     // n_rows = number of work items; row_order (from the plan) lists the rows in degree order so
     // that the 64/LPR rows a wavefront owns need about the same number of steps
     for (int64_t r0 = wave * RPW; r0 < n_rows; r0 += n_waves * RPW) {
@@ -299,10 +381,10 @@ __device__ __forceinline__ void spmm_body(
         int64_t ldd, int relu, int long_threshold, int vec_store, const int32_t *__restrict__ row_order,          \
         int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,  \
         float *__restrict__ partial, int ldp, const float *__restrict__ acc_in, float *__restrict__ acc_out,       \
-        int64_t ld_acc, sgx_epilogue ep
+        int64_t ld_acc, sgx_epilogue ep, int n_multi, int short_first
 #define SGX_SPMM_ARGS                                                                                            \
     n_rows, n_feat, rowptr, col, val, H, h_bytes, ld_bytes, D, ldd, relu, long_threshold, vec_store, row_order,  \
-        split_blocks, n_tasks, task_e0, task_e1, partial, ldp, acc_in, acc_out, ld_acc, ep
+        split_blocks, n_tasks, task_e0, task_e1, partial, ldp, acc_in, acc_out, ld_acc, ep, n_multi, short_first
 
 // Two entry points over the one body, so that a profile tells the stages apart:
 // spmm_kernel = the A.H aggregation (loop_adj), xw_sparse_kernel = X.W with a CSR X (loop_fea, the
@@ -310,13 +392,21 @@ __device__ __forceinline__ void spmm_body(
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_kernel(SGX_SPMM_PARAMS)
 {
-    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_ADJ_STYLE>(SGX_SPMM_ARGS);
+    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_ADJ_STYLE, false>(SGX_SPMM_ARGS);
+}
+
+// the A.H aggregation under a degree-ordered plan whose order ends in one-step rows: those 64 to a wavefront
+// (spmm_short_rows); its own kernel so that the plain one -- the uniform graph's -- keeps its code as measured
+template <typename T, int VEC, int LPR, int CPL, bool BIG>
+__global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void spmm_short_tail_kernel(SGX_SPMM_PARAMS)
+{
+    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_ADJ_STYLE, true>(SGX_SPMM_ARGS);
 }
 
 template <typename T, int VEC, int LPR, int CPL, bool BIG>
 __global__ __launch_bounds__(kBlock, SGX_SPMM_MINWAVES) void xw_sparse_kernel(SGX_SPMM_PARAMS)
 {
-    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_FEA_STYLE>(SGX_SPMM_ARGS);
+    spmm_body<T, VEC, LPR, CPL, BIG, SGX_SPMM_FEA_STYLE, false>(SGX_SPMM_ARGS);
 }
 
 template <typename T>
@@ -378,14 +468,26 @@ int launch_one_impl(const LaunchArgs &a)
     const int n_work = order ? p->n_ordered : a.n_rows;
     const int n_tasks = long_thr > 0 ? p->n_tasks : 0;
     const int split_blocks = (n_tasks + kBlock / 64 - 1) / (kBlock / 64);
-    const int row_blocks = n_work > 0 ? grid_for_rows(n_work, 64 / LPR) : 0;
-    if (split_blocks + row_blocks > 0) {
-        auto kernel = a.fea_stage ? xw_sparse_kernel<T, VEC, LPR, CPL, BIG> : spmm_kernel<T, VEC, LPR, CPL, BIG>;
-        hipLaunchKernelGGL(kernel, dim3(split_blocks + row_blocks), dim3(kBlock), 0,
+    // the one-step tail of a degree order: 64 rows per wavefront (spmm_short_rows); the rows ahead of it keep the sblock path
+    int n_multi = n_work, short_blocks = 0;
+    bool short_tail = false;
+    if constexpr (LPR >= 8 && CPL == 1 && !BIG) {
+        short_tail = order && !a.fea_stage && !sgx_tune().spmm_no_short_tail && p->n_multi >= 0 && p->n_multi < n_work &&
+                     a.n_feat <= LPR * VEC && n_work - p->n_multi >= 4096;
+        if (short_tail) {
+            n_multi = p->n_multi;
+            short_blocks = (int)(((int64_t)(n_work - n_multi) + 64 * (kBlock / 64) - 1) / (64 * (kBlock / 64)));
+        }
+    }
+    const int row_blocks = n_multi > 0 ? grid_for_rows(n_multi, 64 / LPR) : 0;
+    if (split_blocks + row_blocks + short_blocks > 0) {
+        auto kernel = a.fea_stage ? xw_sparse_kernel<T, VEC, LPR, CPL, BIG>
+                                  : (short_tail ? spmm_short_tail_kernel<T, VEC, LPR, CPL, BIG> : spmm_kernel<T, VEC, LPR, CPL, BIG>);
+        hipLaunchKernelGGL(kernel, dim3(split_blocks + row_blocks + short_blocks), dim3(kBlock), 0,
                            a.stream, n_work, a.n_feat, a.rowptr, a.col, (const T *)a.val, (const T *)a.H, a.h_bytes,
                            a.ld_bytes, (T *)a.D, a.ldd, a.relu, long_thr, a.vec_store, order, split_blocks, n_tasks,
                            n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, a.partial, a.ldp, a.acc_in,
-                           a.acc_out, a.ld_acc, a.ep);
+                           a.acc_out, a.ld_acc, a.ep, n_multi, split_blocks + row_blocks);
         SGX_LAUNCH_CHECK();
     }
     if (n_tasks > 0) {

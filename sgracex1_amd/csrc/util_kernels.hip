@@ -291,12 +291,12 @@ void load_tuning()
     t.xw_no_lds = flag("SGX_XW_NO_LDS");
     t.xtg_scalar = flag("SGX_XTG_SCALAR");
     t.xtg_wave_tiles = flag("SGX_XTG_WAVE_TILES");
+    t.spmm_no_short_tail = flag("SGX_SPMM_NO_SHORT_TAIL");
     t.spmm_cpl = num("SGX_SPMM_CPL");
     t.plan_long_threshold = num("SGX_PLAN_LONG_THRESHOLD");
     t.plan_chunk = num("SGX_PLAN_CHUNK");
     const char *rb = getenv("SGX_PLAN_REORDER_BELOW");
     t.plan_reorder_below = rb ? (float)atof(rb) : -1.0f;
-    t.plan_seg = num("SGX_PLAN_SEG");
     g_tuning = t;
     g_tuning_loaded = true;
 }

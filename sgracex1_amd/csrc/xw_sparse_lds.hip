@@ -19,10 +19,12 @@
 // broadcasts it, every lane reads its 16 bytes of that W row from LDS and adds value x W in fp32 in CSR
 // order -- the same fma chain per output element as the gather kernel (spmm_csr.hip), hence the same bits.
 // The groups of a wavefront step together, so a sub-tile of 64 / LPR rows costs its LONGEST row's steps:
-// the 64 rows of a window are therefore sorted by step count inside the wavefront (bitonic network over
-// the lanes) and dealt to the sub-tiles in that order -- the sblock idea of the reference (rows grouped
-// per pipelined loop, K.cpp:826-845) with the grouping chosen by length.  The measured kernel is bound by
-// vector-instruction issue, not by LDS or HBM, which is why the wasted steps matter.
+// the 64 rows of a window are therefore dealt to the sub-tiles by length, longest first -- the sblock idea of
+// the reference (rows grouped per pipelined loop, K.cpp:826-845) with the grouping chosen by length.  The
+// order comes from the plan (sgx_plan::win_order, one byte per row, built once per matrix; round 2 sorted
+// every window inside this kernel, a bitonic network that was 7 % of its vector instructions).  The measured
+// kernel is bound by vector-instruction issue, not by LDS or HBM, which is why the wasted steps and every
+// instruction beside the fmas matter.
 // 16 wavefronts per CU is all a 92 KB table admits, so the latency of the (column, value) stream is
 // covered in software: the entries of the NEXT sub-tile are requested before the current one is summed,
 // the row pointers one window ahead; a row longer than D steps refills its ring as it goes.
@@ -38,6 +40,12 @@ constexpr int kThreads = kWaves * 64;
 #ifndef SGX_XW_LDS_DEPTH
 #define SGX_XW_LDS_DEPTH 8
 #endif
+#ifndef SGX_XW_LDS_SKIP_UNUSED
+#define SGX_XW_LDS_SKIP_UNUSED 1
+#endif
+// an offset that stays out of range after a step's immediate offset (< 4 KiB) is added to it, for the column indices
+// (nnz x 4 bytes) and, halved, for fp16 values (nnz x 2 bytes): the LDS form takes matrices below 2^30 - 2^16 entries
+constexpr unsigned kFarOOB = 0xFFFF0000u;
 constexpr int kDepth = SGX_XW_LDS_DEPTH;                  // steps of a row requested ahead (8 x 4 = 32 entries: S-100M rows hold 18, the longest of 64 about 29)
 constexpr size_t kLdsBudget = 160 * 1024;
 
@@ -58,7 +66,7 @@ template <typename T, int VEC, int LPR, bool FULL>
 __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     int n_rows, int n_feat, int m_fea, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ W, int64_t ldw, int w_vec, T *__restrict__ H, int64_t ldh,
-    int n_split, unsigned nnz_bytes_col, sgx_epilogue ep)
+    int n_split, unsigned nnz_bytes_col, const uint8_t *__restrict__ win_order, sgx_epilogue ep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CP = LPR * VEC;              // columns per slice
@@ -119,6 +127,8 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // provably wave-uniform: scalar control flow below
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_byte *)lds;        // LDS byte address of the tile (what a ds_read takes)
     const int sub = lane % LPR, grp = lane / LPR;
     const int esub = sub % EPS;                          // the entry of a step this lane loads
     const unsigned my_off = (unsigned)sub * 16u;
@@ -143,9 +153,9 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     };
 
     // Loads without divergent branches (a conditional load makes hipcc wait for it at the join, which would
-    // serialise the D requests of a row): row pointers through a clamped index, entries through buffer loads whose
-    // offset is out of range past the end of the row (returns 0, no memory access); the select to the zero row of
-    // the LDS tile happens when the value is used.
+    // serialise the D requests of a row): row pointers through a clamped index, entries through buffer loads that
+    // run on past the end of the row (into the next rows' entries; past the end of the arrays the range check
+    // returns 0); the select to the zero row of the LDS tile and to a zero value happens when a slot is USED.
     const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(col), 0, nnz_bytes_col, 0x00020000);
     const __amdgpu_buffer_rsrc_t val_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(val), 0, (unsigned)(nnz_bytes_col / 4 * sizeof(T)), 0x00020000);
@@ -153,36 +163,26 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     const __amdgpu_buffer_rsrc_t h_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(H, 0, (unsigned)((int64_t)(n_rows - 1) * ldh * (int64_t)sizeof(T)) + (unsigned)n_feat * (unsigned)sizeof(T), 0x00020000);
 
-    // the row pointers of window w: lane l takes row 64 w + l (requested one window ahead)
-    auto load_window = [&](int64_t w, int &e0, int &e1) {
-        const int64_t row = w * 64 + lane;
-        const int64_t rc = row < n_rows ? row : (int64_t)n_rows - 1;
+    // The rows of window w in the plan's order (rank `lane` -> row 64 w + src) and their row pointers: two dependent
+    // requests, spread over two windows -- the order of window w + 2 steps is requested while the row pointers of
+    // window w + 1 step are, whose order arrived a window earlier.
+    auto load_order = [&](int64_t w) -> int {
+        const int64_t wc = w < n_windows ? w : n_windows - 1;
+        return (int)win_order[wc * 64 + lane];
+    };
+    auto load_rows = [&](int64_t w, int src, int &e0, int &e1) {
+        const int64_t row = w * 64 + src;
+        const int64_t rc = row < n_rows ? row : (int64_t)n_rows - 1;       // (a window past the end: clamped, then emptied)
         const int a = rowptr[rc], b = rowptr[rc + 1];
         e0 = a;
         e1 = row < n_rows ? b : a;
     };
-    // sorts the 64 rows of a window by their step count, longest first (ties in row order): a bitonic network on
-    // keys (0xFFFFF - steps) : lane
-    auto sort_window = [&](int64_t w, int e0, int e1, Window &win) {
-        int steps = (e1 - e0 + EPS - 1) / EPS;
-        steps = steps > 0xFFFFF ? 0xFFFFF : steps;
-        unsigned key = ((unsigned)(0xFFFFF - steps) << 6) | (unsigned)lane;
-#pragma unroll
-        for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const unsigned other = (unsigned)__shfl_xor((int)key, j);
-                const bool up = (lane & k) == 0 || k == 64;
-                const bool lower = (lane & j) == 0;
-                const unsigned lo = key < other ? key : other, hi = key < other ? other : key;
-                key = (lower == up) ? lo : hi;
-            }
-        }
+    auto make_window = [&](int64_t w, int src, int e0, int e1, Window &win) {
         win.base = w * 64;
-        win.src = (int)(key & 63u);
-        win.steps = 0xFFFFF - (int)(key >> 6);
-        win.e0 = __shfl(e0, win.src);
-        win.e1 = __shfl(e1, win.src);
+        win.src = src;
+        win.e0 = e0;
+        win.e1 = e1;
+        win.steps = (e1 - e0 + EPS - 1) / EPS;
     };
     // sub-tile t of a window: group g takes the row of rank t * RPW + g; nsteps = the sub-tile's longest row
     auto sub_meta = [&](const Window &win, int t, Meta &m, int &nsteps) {
@@ -193,68 +193,110 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
         m.live = m.r < n_rows;
         nsteps = __builtin_amdgcn_readlane(win.steps, t * RPW);
     };
-    // One (column, value) request.  `wanted` is wave-uniform: when false the address arithmetic is skipped and the
-    // loads go out of range -- they are still ISSUED, so that the number of vector-memory operations between a
-    // request and its use is the same on every path (hipcc's s_waitcnt counts stay exact: with a varying count it
-    // falls back to waiting for everything, the newest requests included, which is the prefetch undone).
-    // select_now = false leaves the raw column in c (0 past the end of the row) for the caller to redirect when it
-    // uses the slot: inside the step loop an immediate select would wait for the load it belongs to.
-    auto fetch = [&](bool wanted, int idx, int e1, unsigned &c, T &a, bool select_now = true) {
-        unsigned off = kOOB;
-        bool ok = false;
-        if (wanted) {
-            ok = idx < e1;
-            off = ok ? (unsigned)idx * 4u : kOOB;
-        }
-        const unsigned cc = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
-        if constexpr (sizeof(T) == 2) {
-            // kOOB / 2 is out of range for the value buffer too (nnz < 2^30)
-            const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0);
-            a = __builtin_bit_cast(T, h);                 // 0 past the end of the row
-        } else {
-            a = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
-        }
-        c = (ok || !select_now) ? cc : zero_col;
-    };
     // A UNIT of work = D consecutive steps of one sub-tile: chunk k covers steps [k D, k D + D).  Almost every
     // sub-tile is one unit; rows over D steps continue in further units of the same sub-tile with the sums carried
-    // in registers.  Every unit runs the same straight-line code with the same number of memory operations.
+    // in registers.  Every unit runs the same straight-line code with the same number of memory operations
+    // (hipcc's s_waitcnt counts stay exact: with a varying count it falls back to waiting for everything, the
+    // newest requests included, which is the prefetch undone): all D (column, value) requests of a unit are
+    // issued, from ONE base offset with the step as the instruction's immediate offset -- no per-step address or
+    // range arithmetic; slots past the end of the row are dealt with when they are used.
     auto issue_entries = [&](const Meta &m, int k, int nsteps, Entries &en) {
+        const unsigned base = (unsigned)(m.e0 + k * (D * EPS) + esub) * 4u;
 #pragma unroll
-        for (int d = 0; d < D; ++d) fetch(k * D + d < nsteps, m.e0 + (k * D + d) * EPS + esub, m.e1, en.c[d], en.a[d]);
+        for (int d = 0; d < D; ++d) {
+#if SGX_XW_LDS_SKIP_UNUSED
+            // steps behind the sub-tile's last one (a wave-uniform condition: one select) go out of range: the request is
+            // still ISSUED, but the texture-address unit does not look its 64 lanes up in the cache -- with those lookups
+            // the unit (67 % busy before) became the limit, which cost more than the per-step address arithmetic saved
+            const unsigned off = (k * D + d < nsteps) ? base : kFarOOB;
+#else
+            const unsigned off = base;
+#endif
+            en.c[d] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off + (unsigned)(d * EPS * 4), 0, 0);
+            if constexpr (sizeof(T) == 2) {
+                const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(val_rsrc, (off >> 1) + (unsigned)(d * EPS * 2), 0, 0);
+                en.a[d] = __builtin_bit_cast(T, h);
+            } else {
+                en.a[d] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off + (unsigned)(d * EPS * 4), 0, 0));
+            }
+        }
     };
 
     float acc[VEC];
     // the sums of one unit; after a sub-tile's last unit its rows are stored
     auto compute = [&](const Meta &cur, int k, int nsteps, Entries &en) {
-        if (k == 0) {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (k * D + d >= nsteps) break;
-            const unsigned rr = en.c[d] * ROWB;
-            const unsigned a = __builtin_bit_cast(unsigned, Elem<T>::to_f32(en.a[d]));
-            u32x4 raw[EPS];
-            float aa[EPS];
+        // this lane's slot of step d of the unit lies inside its row while rem > d EPS
+        const int rem = cur.e1 - cur.e0 - k * (D * EPS) - esub;
+        // One step = the broadcasts and the EPS reads of W rows from LDS (prep), then EPS x VEC fmas.  The reads of step
+        // d + 1 are issued BEFORE the fmas of step d.  Every step ends in a wave-uniform branch (the sub-tile's step
+        // count), and hipcc sinks loads that are not used before such a branch into the block behind it -- with the reads
+        // there each step waited out its own LDS round trip (SQ_WAIT_INST_ANY was 1.9 x the cycles that issued vector
+        // instructions).  So the reads are inline assembly (never moved), and so is the wait before a step's fmas: it
+        // names the step's registers as read-write operands, which keeps every consumer behind it, and counts what may
+        // stay outstanding -- the EPS reads of the NEXT step (LDS operations return in order; operations the compiler
+        // issues in between only make the count stricter; there is no scalar load inside the loop).  Two named register
+        // sets, indexed by the unrolled step's parity.
+        auto lds_read = [&](u32x4 &dst, unsigned byte_off) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_base + byte_off) : "memory");
+        };
+        auto prep = [&](int d, u32x4 (&raw)[EPS], float (&aa)[EPS]) {
+            // a slot past the end of the row holds another row's entry (or 0 past the arrays): the zero row of the
+            // tile and a zero value, so that a non-finite neighbour never leaks
+            const bool ok = rem > d * EPS;
+            const unsigned rr = (ok ? en.c[d] : zero_col) * ROWB;
+            const unsigned a = __builtin_bit_cast(unsigned, Elem<T>::to_f32(ok ? en.a[d] : (T)0));
             if constexpr (EPS == 4) {
-                raw[0] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<4, 0>(rr) + my_off);
-                raw[1] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<4, 1>(rr) + my_off);
-                raw[2] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<4, 2>(rr) + my_off);
-                raw[3] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<4, 3>(rr) + my_off);
+                lds_read(raw[0], step_bcast<4, 0>(rr) + my_off);
+                lds_read(raw[1], step_bcast<4, 1>(rr) + my_off);
+                lds_read(raw[2], step_bcast<4, 2>(rr) + my_off);
+                lds_read(raw[3], step_bcast<4, 3>(rr) + my_off);
                 aa[0] = __builtin_bit_cast(float, step_bcast<4, 0>(a));
                 aa[1] = __builtin_bit_cast(float, step_bcast<4, 1>(a));
                 aa[2] = __builtin_bit_cast(float, step_bcast<4, 2>(a));
                 aa[3] = __builtin_bit_cast(float, step_bcast<4, 3>(a));
             } else {
-                raw[0] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<2, 0>(rr) + my_off);
-                raw[1] = *reinterpret_cast<const u32x4 *>(lds + step_bcast<2, 1>(rr) + my_off);
+                lds_read(raw[0], step_bcast<2, 0>(rr) + my_off);
+                lds_read(raw[1], step_bcast<2, 1>(rr) + my_off);
                 aa[0] = __builtin_bit_cast(float, step_bcast<2, 0>(a));
                 aa[1] = __builtin_bit_cast(float, step_bcast<2, 1>(a));
             }
+        };
+        // waits until at most `pending` LDS operations are outstanding; the registers of the step about to be summed
+        // pass through it
+        auto arrive = [&](u32x4 (&raw)[EPS], bool next_in_flight) {
+            if constexpr (EPS == 4) {
+                if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
+            } else {
+                if (next_in_flight) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(raw[0]), "+v"(raw[1]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]) :: "memory");
+            }
+        };
+        u32x4 raw_even[EPS], raw_odd[EPS];
+        float aa_even[EPS], aa_odd[EPS];
+        prep(0, raw_even, aa_even);
 #pragma unroll
-            for (int t = 0; t < EPS; ++t) Fma<T, VEC>::run(acc, aa[t], raw[t]);
+        for (int d = 0; d < D; ++d) {
+            if (k * D + d >= nsteps) break;
+            u32x4 (&raw)[EPS] = (d & 1) ? raw_odd : raw_even;
+            float (&aa)[EPS] = (d & 1) ? aa_odd : aa_even;
+            // (requested for the step behind the sub-tile's last one too: it reads the zero row and is never summed)
+            if (d + 1 < D) prep(d + 1, (d & 1) ? raw_even : raw_odd, (d & 1) ? aa_even : aa_odd);
+            arrive(raw, d + 1 < D);
+            // the first entry of a row STARTS the sums (fma onto a literal +0: the same value as an fma onto a zeroed
+            // register, without the eight moves that zero it)
+            if (d == 0 && k == 0) FmaInit<T, VEC>::run(acc, aa[0], raw[0]);
+            else Fma<T, VEC>::run(acc, aa[0], raw[0]);
+#pragma unroll
+            for (int t = 1; t < EPS; ++t) Fma<T, VEC>::run(acc, aa[t], raw[t]);
+        }
+        // reads still in flight when the unit ends early (the step behind the last one): they must land before their
+        // registers are reused
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // a sub-tile without a step (64 empty rows): zeros
+        if (nsteps == 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
         }
         // The stores go through a buffer resource over H with an out-of-range offset for lanes that have nothing to
         // store (rows past the end; units that are not their sub-tile's last): the same number of store instructions
@@ -280,19 +322,26 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
 
     int64_t w = (int64_t)stream * kWaves + wave;
     if (w >= n_windows) return;
-    int e0_raw, e1_raw;                   // the next window's row pointers, in flight
     Window win;
-    load_window(w, e0_raw, e1_raw);
-    sort_window(w, e0_raw, e1_raw, win);
-    load_window(w + win_step, e0_raw, e1_raw);
+    int src_nxt;                          // the order of window w + 1 step (arrived)
+    {
+        const int src0 = load_order(w);
+        src_nxt = load_order(w + win_step);
+        int a0, b0;
+        load_rows(w, src0, a0, b0);
+        make_window(w, src0, a0, b0, win);
+    }
+    int src_raw = load_order(w + 2 * win_step);      // in flight: the order of window w + 2 steps ...
+    int e0_raw, e1_raw;                              // ... and the row pointers of window w + 1 step
+    load_rows(w + win_step, src_nxt, e0_raw, e1_raw);
     Meta m_cur, m_nxt;
     int n_cur, n_nxt, k_cur = 0, k_nxt, t = 0;
     Entries en0, en1;
     sub_meta(win, 0, m_cur, n_cur);
     issue_entries(m_cur, 0, n_cur, en0);
     // One unit per call: the next unit's entries are requested (the same sub-tile's next chunk, the window's next
-    // sub-tile, or the first sub-tile of the next window, whose row pointers arrived earlier and are sorted now), then
-    // the current unit is summed.  The two entry rings alternate.  Returns false after the stream's last unit.
+    // sub-tile, or the first sub-tile of the next window, whose row pointers arrived earlier), then the current unit
+    // is summed.  The two entry rings alternate.  Returns false after the stream's last unit.
     auto advance = [&](Entries &en_cur, Entries &en_nxt) -> bool {
         bool more = true;
         if ((k_cur + 1) * D < n_cur) {
@@ -308,12 +357,14 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
             k_nxt = 0;
             w += win_step;
             more = w < n_windows;
-            // (a window past the end sorts clamped row pointers: every row empty, nothing requested, nothing stored)
-            sort_window(w, e0_raw, e1_raw, win);
+            // (a window past the end has clamped row pointers: every row empty, nothing stored)
+            make_window(w, src_nxt, e0_raw, e1_raw, win);
+            src_nxt = src_raw;
             sub_meta(win, 0, m_nxt, n_nxt);
         }
         // requested on every call (mostly re-reads of cached lines): a fixed number of loads per call
-        load_window(w + win_step, e0_raw, e1_raw);
+        src_raw = load_order(w + 2 * win_step);
+        load_rows(w + win_step, src_nxt, e0_raw, e1_raw);
         issue_entries(m_nxt, k_nxt, n_nxt, en_nxt);
         compute(m_cur, k_cur, n_cur, en_cur);
         m_cur = m_nxt;
@@ -341,7 +392,7 @@ int device_cus()
 
 template <typename T, int VEC, int LPR, bool FULL>
 int launch_lds_impl(int n_work, int n_feat, int m_fea, const int32_t *rowptr, const int32_t *col, const void *val, const void *W,
-               int64_t ldw, void *H, int64_t ldh, int64_t nnz, sgx_epilogue ep, hipStream_t stream)
+               int64_t ldw, void *H, int64_t ldh, int64_t nnz, const uint8_t *win_order, sgx_epilogue ep, hipStream_t stream)
 {
     auto kernel = xw_sparse_lds_kernel<T, VEC, LPR, FULL>;
     const size_t lds_bytes = (size_t)(m_fea + 1) * LPR * 16;
@@ -362,18 +413,18 @@ int launch_lds_impl(int n_work, int n_feat, int m_fea, const int32_t *rowptr, co
     if (grid < 8 * n_split) grid = 8 * n_split;
     const int w_vec = ((uintptr_t)W % 16 == 0) && ((ldw * (int64_t)sizeof(T)) % 16 == 0);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds_bytes, stream, n_work, n_feat, m_fea, rowptr, col,
-                       (const T *)val, (const T *)W, ldw, w_vec, (T *)H, ldh, n_split, (unsigned)(nnz * 4), ep);
+                       (const T *)val, (const T *)W, ldw, w_vec, (T *)H, ldh, n_split, (unsigned)(nnz * 4), win_order, ep);
     SGX_LAUNCH_CHECK();
     return SGX_OK;
 }
 
 template <typename T, int VEC, int LPR>
 int launch_lds(int n_work, int n_feat, int m_fea, const int32_t *rowptr, const int32_t *col, const void *val, const void *W,
-               int64_t ldw, void *H, int64_t ldh, int64_t nnz, sgx_epilogue ep, hipStream_t stream)
+               int64_t ldw, void *H, int64_t ldh, int64_t nnz, const uint8_t *win_order, sgx_epilogue ep, hipStream_t stream)
 {
     const bool full = n_feat % (LPR * VEC) == 0 && ((uintptr_t)H % 16 == 0) && ((ldh * (int64_t)sizeof(T)) % 16 == 0);
-    return full ? launch_lds_impl<T, VEC, LPR, true>(n_work, n_feat, m_fea, rowptr, col, val, W, ldw, H, ldh, nnz, ep, stream)
-                : launch_lds_impl<T, VEC, LPR, false>(n_work, n_feat, m_fea, rowptr, col, val, W, ldw, H, ldh, nnz, ep, stream);
+    return full ? launch_lds_impl<T, VEC, LPR, true>(n_work, n_feat, m_fea, rowptr, col, val, W, ldw, H, ldh, nnz, win_order, ep, stream)
+                : launch_lds_impl<T, VEC, LPR, false>(n_work, n_feat, m_fea, rowptr, col, val, W, ldw, H, ldh, nnz, win_order, ep, stream);
 }
 
 // lanes per row of the LDS tile: the widest slice (power-of-two lanes x 16 bytes) whose (M_fea + 1) rows fit
@@ -395,7 +446,7 @@ int choose_lpr(int dtype, int m_fea, int n_feat)
 bool sgx_xw_sparse_lds_applicable(int dtype, int n_rows, int m_fea, int n_feat, int64_t ldh, const sgx_plan *plan)
 {
     if (sgx_tune().xw_sparse_no_lds) return false;         // tuning override (tools/xw_sparse_probe.py)
-    if (!plan || plan->n_tasks > 0 || plan->nnz < ((int64_t)1 << 20) || plan->nnz >= ((int64_t)1 << 30) || n_rows < 4096)
+    if (!plan || !plan->win_order || plan->n_tasks > 0 || plan->nnz < ((int64_t)1 << 20) || plan->nnz >= ((int64_t)1 << 30) - 65536 || n_rows < 4096)
         return false;                                 // (32-bit buffer offsets into columnIndex: nnz x 4 bytes below 4 GiB)
     if ((unsigned long long)n_rows * (unsigned long long)ldh * (dtype == SGX_F16 ? 2ull : 4ull) >= 0xFFF00000ull)
         return false;                                 // H is stored through 32-bit buffer offsets too
@@ -410,14 +461,14 @@ int sgx_xw_sparse_lds(int dtype, int n_rows, int m_fea, int n_feat, const int32_
                       const void *values, const void *W, int64_t ldw, void *H, int64_t ldh, const sgx_plan *plan,
                       sgx_epilogue ep, hipStream_t stream)
 {
-    const int n_work = n_rows;            // the kernel orders rows itself (inside windows of 64): the plan's order is not used
+    const int n_work = n_rows;            // rows are dealt by length inside windows of 64 (plan->win_order), not in the plan's degree order
     const int lpr = choose_lpr(dtype, m_fea, n_feat);
 #define SGX_LDS_CASE(L)                                                                                                     \
     case L:                                                                                                                 \
         return dtype == SGX_F16 ? launch_lds<f16, 8, L>(n_work, n_feat, m_fea, rowPtr, columnIndex, values, W, ldw, H, ldh, \
-                                                        plan->nnz, ep, stream)                                                \
+                                                        plan->nnz, plan->win_order, ep, stream)                               \
                                 : launch_lds<float, 4, L>(n_work, n_feat, m_fea, rowPtr, columnIndex, values, W, ldw, H,    \
-                                                          ldh, plan->nnz, ep, stream);
+                                                          ldh, plan->nnz, plan->win_order, ep, stream);
     switch (lpr) {
         SGX_LDS_CASE(2)
         SGX_LDS_CASE(4)

@@ -116,7 +116,7 @@ class Plan:
     def reordered(self):
         return bool(lib.sgx_plan_reordered(self._h))
 
-    ARRAYS = ("long_row", "long_first", "task_row", "task_e0", "task_e1", "row_order")
+    ARRAYS = ("long_row", "long_first", "task_row", "task_e0", "task_e1", "row_order", "win_order")
 
     def export(self, name):
         """One of the schedule's device arrays (ARRAYS) as an int32 tensor -- for inspection and tests."""
@@ -129,6 +129,8 @@ class Plan:
             got = lib.sgx_plan_export(self._h, which, _ptr(out), int(n), _stream())
             if got < 0:
                 check(int(got), "sgx_plan_export")
+        if name == "win_order":                 # bytes: the row (0..63) of every rank of every 64-row window
+            return out.view(torch.uint8)
         return out
 
     def __del__(self, _destroy=lib.sgx_plan_destroy):        # bound at definition: module globals are gone at shutdown
@@ -396,7 +398,8 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
     Returns D [N, P] (and (E, S) per-edge tensors when want_edge_outputs with GAT).
     quant: a quant.QuantConstants -- run the layer with the quantised arithmetic of the SGRACE
     bitstream (fp32 tensors only); quant_int8: with dense features, X and W go to the int8 matrix cores as the integer
-    codes of their grids (SGX_QUANT_INT8: exact int32 sums, X read as bytes); adj_quantized: adj.val already went through the quantiser;
+    codes of their grids (SGX_QUANT_INT8: exact int32 sums, X read as bytes), "auto" = where that is the faster form
+    (SGX_QUANT_INT8_AUTO: M_fea > 128); adj_quantized: adj.val already went through the quantiser;
     cache_quantized_adj: quantise the adjacency once per graph on the host side instead of inside
     every call (always done for GAT, whose mask decides how rows without a live edge are treated).
     order: "reference" -- X.W first, as the reference's dataflow; "aggregate_first" -- D = act((A.X).W), which
@@ -466,7 +469,9 @@ def layer_forward(adj, fea, Wt, relu=False, gat_attention=None, alpha=0.2, want_
         d.ev_agg_begin, d.ev_agg_end = agg_events
     if quant is not None:
         qs = quant.as_struct(nnz_adj=adj.nnz, nnz_fea=fea.nnz if gemm_mode == 0 else 0, adj_done=adj_quantized)
-        if quant_int8:
+        if quant_int8 == "auto":
+            qs.flags |= _lib.SGX_QUANT_INT8_AUTO
+        elif quant_int8:
             qs.flags |= _lib.SGX_QUANT_INT8
         d.quant = ctypes.pointer(qs)
     nbytes = lib.sgx_layer_workspace_bytes(ctypes.byref(d))

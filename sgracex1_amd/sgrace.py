@@ -135,11 +135,15 @@ class FPYNQ_GAT(torch.autograd.Function):
             else:
                 fea = fea.to(dt).contiguous()
             my_ip.alpha = self.alpha
+            # config.hardware_quantize: the bitstream's own quantiser -- integer operands on the int8 matrix cores where
+            # they are the faster form (dense features wider than 128 columns; sgx.h SGX_QUANT_INT8_AUTO);
+            # config.fake_quantization alone: the fp32 emulation of the grid, as the reference states it
+            int8 = "auto" if (qc is not None and config.hardware_quantize) else False
             if ctx.gat:
                 out, E, S = my_ip.run_layer(A, fea, Wt, attention=attention.detach().to(dt).reshape(-1).contiguous(),
-                                            want_edge_outputs=True, quant=qc)
+                                            want_edge_outputs=True, quant=qc, quant_int8=int8)
             else:
-                out, E, S = my_ip.run_layer(A, fea, Wt, quant=qc), None, None
+                out, E, S = my_ip.run_layer(A, fea, Wt, quant=qc, quant_int8=int8), None, None
             ctx.csr = A
             ctx.save_for_backward(input, weights, out, *([E, S] if ctx.gat else []))
             return out.float()                                            # SG.py:543 `.float()`

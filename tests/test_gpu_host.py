@@ -73,6 +73,32 @@ def test_notebook_register_map_flow_citeseer(oracle):
     want = oracle.layer_f64(0, 0, (d["adj"][0], d["adj"][1], h(d["adj"][2])), (d["fea"][0], d["fea"][1], h(d["fea"][2])),
                             h(np.ascontiguousarray(d["w"][:, :P_w].T)), h_round=2)
     np.testing.assert_allclose(result.astype(np.float32), want, rtol=1e-2, atol=2e-3)
+    # The buffers live in pinned host memory and keep device mirrors: the first start moved everything, a
+    # second start with untouched buffers moves nothing up, and a second LAYER on the same graph -- new features and
+    # weights written by slice assignment, as MOL cell 16 does -- uploads those and not one byte of the adjacency.
+    st = my_ip.transfer_stats
+    adj_bytes = rowPtr_adj_buffer.nbytes + columnIndex_adj_buffer.nbytes + values_adj_buffer.nbytes
+    assert st["uploaded_bytes"] >= adj_bytes and st["reused_bytes"] == 0 and st["downloaded_bytes"] == D_buffer.nbytes
+    up0 = st["uploaded_bytes"]
+    run_kernel()
+    assert st["uploaded_bytes"] == up0 and st["reused_bytes"] >= adj_bytes
+    assert np.array_equal(np.asarray(D_buffer), result)
+    values_fea_buffer[0:NNZ_fea] = d["fea_val"].astype(np.float16)         # (the same values again: a write is a write)
+    B_buffer[:] = w[:, :P_w].T
+    reused0 = st["reused_bytes"]
+    run_kernel()
+    assert st["uploaded_bytes"] - up0 == NNZ_fea * 2 + B_buffer.nbytes            # the slice that is read, not the 200000-element buffer
+    assert st["reused_bytes"] - reused0 >= adj_bytes + rowPtr_fea_buffer.nbytes + columnIndex_fea_buffer.nbytes
+    np.testing.assert_array_equal(np.asarray(D_buffer), result)
+    # a write that goes around the buffer object (no slice assignment, no flush): the content stamp catches it
+    keep = values_adj_buffer[0].copy()
+    np.asarray(values_adj_buffer)[0] = 0
+    run_kernel()
+    changed = np.asarray(D_buffer) != result
+    assert changed.any() and st["uploaded_bytes"] - up0 >= NNZ_fea * 2 + B_buffer.nbytes + values_adj_buffer.nbytes
+    values_adj_buffer[0:1] = keep
+    run_kernel()
+    assert np.array_equal(np.asarray(D_buffer), result)
     assert not profiling_buffer[:15].any()                                 # cells 39-40: all zero
     # relu register and the dense mode through the same registers
     rm.relu = 1

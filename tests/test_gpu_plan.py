@@ -138,3 +138,31 @@ def test_plan_drives_the_same_sums():
     cut[A.plan.export("long_row").long()] = True
     assert torch.equal(with_plan[~cut], without[~cut])
     torch.testing.assert_close(with_plan[cut].float(), without[cut].float(), rtol=2e-3, atol=2e-3)
+
+
+def test_plan_window_order_of_the_sparse_feature_stage():
+    """win_order: the rows of every 64-row window by length, longest first, ties in row order -- what the LDS form of the
+    sparse X.W stage deals to its sub-tiles (xw_sparse_lds.hip).  Built for matrices of 2^20 entries and more without cut
+    rows; the last window is ragged (rows past the end count as empty)."""
+    from sgracex1_amd import ops
+    rng = np.random.default_rng(77)
+    n = 70_003
+    deg = rng.poisson(18, n)
+    deg[rng.integers(0, n, 500)] = 0
+    rp = _rowptr(deg)
+    assert rp[-1] >= 1 << 20
+    plan = ops.Plan(torch.as_tensor(rp.astype(np.int32), device=dev))
+    assert plan.long_rows == 0
+    got = plan.export("win_order").cpu().numpy()
+    n_win = (n + 63) // 64
+    assert got.dtype == np.uint8 and got.size == n_win * 64
+    padded = np.concatenate([deg, np.zeros(n_win * 64 - n, np.int64)]).reshape(n_win, 64)
+    want = np.argsort(-padded, axis=1, kind="stable").astype(np.uint8)
+    np.testing.assert_array_equal(got.reshape(n_win, 64), want)
+    # no such array where the LDS form cannot run: a small matrix, a matrix with cut rows
+    small = ops.Plan(torch.as_tensor(_rowptr(rng.poisson(3, 5000)).astype(np.int32), device=dev))
+    assert small.export("win_order").numel() == 0
+    hub = deg.copy()
+    hub[5] = 200_000
+    cut = ops.Plan(torch.as_tensor(_rowptr(hub).astype(np.int32), device=dev))
+    assert cut.long_rows == 1 and cut.export("win_order").numel() == 0

@@ -274,3 +274,73 @@ def test_quantised_layer_with_integer_operands(bits, gat, m):
     # a sparse X keeps the fp32 form (the flag is ignored where it does not apply)
     Xs = ops.Csr.from_dense(X, torch.float32)
     assert torch.equal(ops.layer_forward(A, Xs, Wt, quant_int8=True, **kw), ops.layer_forward(A, Xs, Wt, **kw))
+
+
+def _workspace_bytes(M_fea, P, flags):
+    """sgx_layer_workspace_bytes of a dense-feature quantised layer: the integer form carves byte code matrices
+    (M_fea rounded up to 16 per row) where the fp32 form carves float copies -- which form the library chose shows there."""
+    import ctypes
+    from sgracex1_amd import _lib, quant
+    d = _lib.LayerDesc()
+    d.gemm_mode, d.relu, d.gat_mode = 1, 1, 0
+    d.N_adj = d.M_adj = 1000
+    d.M_fea, d.P_w, d.dtype, d.acc_mode, d.spmm_block = M_fea, P, _lib.SGX_F32, _lib.SGX_ACC_F32, 1
+    qs = quant.constants(8).as_struct(nnz_adj=5000, adj_done=True)
+    qs.flags |= flags
+    d.quant = ctypes.pointer(qs)
+    return _lib.lib.sgx_layer_workspace_bytes(ctypes.byref(d))
+
+
+def test_integer_operands_are_chosen_by_shape():
+    """SGX_QUANT_INT8_AUTO: the integer form exactly where the dense features are wider than 128 columns (the fp32
+    product's weights-stationary kernels end there); a forced flag and no flag at all are the two forms themselves."""
+    from sgracex1_amd import _lib
+    for M in (64, 128):
+        assert _workspace_bytes(M, 64, _lib.SGX_QUANT_INT8_AUTO) == _workspace_bytes(M, 64, 0) != _workspace_bytes(M, 64, _lib.SGX_QUANT_INT8)
+    for M in (129, 200, 602):
+        assert _workspace_bytes(M, 64, _lib.SGX_QUANT_INT8_AUTO) == _workspace_bytes(M, 64, _lib.SGX_QUANT_INT8) != _workspace_bytes(M, 64, 0)
+    # outputs wider than the integer kernel takes (P_w > 256) keep the fp32 form under either flag
+    assert _workspace_bytes(602, 300, _lib.SGX_QUANT_INT8_AUTO) == _workspace_bytes(602, 300, 0) == _workspace_bytes(602, 300, _lib.SGX_QUANT_INT8)
+
+
+@pytest.mark.parametrize("gat", [0, 1])
+def test_hardware_quantize_reaches_the_int8_matrix_cores_through_the_library_layer(gat, monkeypatch):
+    """config.hardware_quantize = 1; init_SGRACE(); GATConv_SGRACE(...): a dense-feature layer wider than 128 columns
+    runs its X.W on the int8 matrix cores (the flag FPYNQ_GAT hands to the layer is recorded), and -- 200 columns of
+    8-bit codes sum below 2^24 -- gives the bits of the fp32 emulation (config.fake_quantization alone), forward and
+    backward."""
+    from sgracex1_amd import config, ops, sgrace
+    n, m, p = 600, 200, 32
+    adj, x, w, att = _graph_case(n, m, p, 123 + gat)
+    idx = adj.nonzero().t()
+    norm = adj[idx[0], idx[1]]
+    seen = []
+    real = ops.layer_forward
+
+    def spy(*a, **kw):
+        seen.append((kw.get("quant_int8"), a[1].shape[1] if isinstance(a[1], torch.Tensor) else None))
+        return real(*a, **kw)
+
+    monkeypatch.setattr(ops, "layer_forward", spy)
+    old = (config.acc, config.fake_quantization, config.hardware_quantize, config.w_qbits, config.compute_attention,
+           config.float_type, config.device)
+    outs = {}
+    try:
+        for hw in (0, 1):
+            config.acc, config.fake_quantization, config.hardware_quantize, config.w_qbits = 1, 1, hw, 8
+            config.compute_attention, config.float_type = gat, np.float32
+            sgrace.init_SGRACE()
+            layer = sgrace.GATConv_SGRACE(m, p).to(dev)
+            with torch.no_grad():
+                layer.weight.copy_(w), layer.attention.copy_(att)
+            seen.clear()
+            out = layer(gat, 1, 1, x.to(dev), idx.to(dev), norm.to(dev), adj.to(dev).to_sparse())      # dense = 1
+            out.sum().backward()
+            assert seen == [("auto" if hw else False, m)]
+            outs[hw] = (out.detach().clone(), layer.weight.grad.detach().clone())
+        assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+        assert outs[1][0].abs().max() > 0
+    finally:
+        (config.acc, config.fake_quantization, config.hardware_quantize, config.w_qbits, config.compute_attention,
+         config.float_type, config.device) = old
+        sgrace.init_SGRACE()

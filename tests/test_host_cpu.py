@@ -24,17 +24,46 @@ def test_allocate_and_physical_addresses():
     assert a.shape == (100,) and a.dtype == np.int32 and not a.any()
     assert b.shape == (4, 8) and b.dtype == np.float16
     assert a.physical_address != b.physical_address
-    flat, dt = P._resolve(a.physical_address)
+    flat, dt, win, off = P._resolve(a.physical_address)
     flat[3] = 7
-    assert a[3] == 7 and dt == np.int32
+    assert a[3] == 7 and dt == np.int32 and off == 0 and win is a._win
     # an address inside a buffer (the notebooks add byte offsets for D2..D4, MMN cell 31)
-    flat2, _ = P._resolve(b.physical_address + 2 * 8 * 2)
+    flat2, _, win2, off2 = P._resolve(b.physical_address + 2 * 8 * 2)
     flat2[0] = 1.5
-    assert b[2, 0] == np.float16(1.5)
+    assert b[2, 0] == np.float16(1.5) and off2 == 16 and win2 is b._win
     assert b[1:].physical_address == b.physical_address + 16
     a.freebuffer()
     with pytest.raises(ValueError):
         P._resolve(a.physical_address)
+
+
+def test_buffer_change_tracking():
+    """What decides whether a buffer's device mirror is uploaded again: a write counter that every slice assignment
+    through the buffer or any of its views bumps (how the reference fills its buffers), flush(), and a content stamp for
+    writes that go around the buffer object."""
+    from sgracex1_amd import pynq_shim as P
+    a = P.allocate(300_000, dtype=np.float16)
+    v0 = a._win.version
+    a[0:10] = 1.0
+    assert a._win.version == v0 + 1
+    view = a[100:200]
+    view[:] = 2.0                                   # a view shares the buffer's counter
+    assert a._win.version == v0 + 2 and a[150] == 2
+    a.flush()
+    assert a._win.version == v0 + 3
+    s0 = P._content_stamp(np.asarray(a))
+    np.asarray(a)[5] = 9                            # around the counter: the stamp of the first 4 KB moves
+    assert a._win.version == v0 + 3 and P._content_stamp(np.asarray(a)) != s0
+    s1 = P._content_stamp(np.asarray(a))
+    np.asarray(a)[-3] = 4                           # ... and of the last 4 KB
+    assert P._content_stamp(np.asarray(a)) != s1
+    small = P.allocate(1000, dtype=np.int32)        # small buffers are fingerprinted whole
+    s2 = P._content_stamp(np.asarray(small))
+    np.asarray(small)[500] = 1
+    assert P._content_stamp(np.asarray(small)) != s2
+    # the pinned storage is zeroed like np.zeros, and a buffer of another dtype or shape is a view of it
+    m = P.allocate(shape=(3, 5), dtype=np.int64)
+    assert m.shape == (3, 5) and not m.any() and m._win.storage.numel() >= 3 * 5 * 8
 
 
 def test_register_map_semantics():

@@ -46,16 +46,40 @@ rm.values_adj1_offset_1 = bufs["va"].physical_address
 rm.values_fea1_offset_1 = bufs["x"].physical_address
 rm.B_offset_1 = bufs["B"].physical_address
 rm.D1_offset_1 = bufs["D"].physical_address
-rm.CTRL.AP_START = 1
-t0 = time.perf_counter()
-for _ in range(3):
+def start():
     rm.CTRL.AP_START = 1
     while rm.CTRL.AP_DONE == 0:
         pass
-t_host = (time.perf_counter() - t0) / 3
+
+
+def timed_start():
+    before = dict(ip.transfer_stats)
+    t0 = time.perf_counter()
+    start()
+    dt = time.perf_counter() - t0
+    return dt, {k: ip.transfer_stats[k] - before[k] for k in before}
+
+
+# first start: every buffer crosses PCIe (pinned memory, asynchronous copies) and the adjacency gets its row plan;
+# second start with nothing changed: the mirrors are current, only D comes back;
+# a new layer on the same graph (X and W rewritten, as between the two layers of GCN_PYNQ): the adjacency stays in HBM
+t_first, moved_first = timed_start()
+t_same, moved_same = timed_start()
+bufs["x"][:] = bufs["x"][::-1]
+bufs["B"][:] = -np.asarray(bufs["B"])
+t_newx, moved_newx = timed_start()
+bufs["x"][:] = X.cpu().numpy().reshape(-1)
+bufs["B"][:] = Wt.cpu().numpy().reshape(-1)
+start()
 assert np.array_equal(np.asarray(bufs["D"]).reshape(n, P), out.cpu().numpy())
-host_bytes = (n + 1) * 4 + A.nnz * 6 + n * f_in * 2 + P * f_in * 2 + n * P * 2
+adj_bytes = (n + 1) * 4 + A.nnz * 6
+host_bytes = adj_bytes + n * f_in * 2 + P * f_in * 2 + n * P * 2
 print(json.dumps({"nodes": n, "edges": A.nnz, "f_in": f_in, "P": P,
                   "device_resident_ms": t_dev * 1e3, "device_resident_edges_per_s": A.nnz / t_dev,
-                  "host_buffers_ms": t_host * 1e3, "host_buffers_edges_per_s": A.nnz / t_host,
-                  "host_bytes_moved": host_bytes, "host_path_GBps": host_bytes / t_host / 1e9}))
+                  "host_buffers_first_start_ms": t_first * 1e3, "first_start_bytes": moved_first,
+                  "first_start_GBps": (moved_first["uploaded_bytes"] + moved_first["downloaded_bytes"]) / t_first / 1e9,
+                  "host_buffers_unchanged_ms": t_same * 1e3, "unchanged_bytes": moved_same,
+                  "host_buffers_new_features_same_graph_ms": t_newx * 1e3, "new_features_bytes": moved_newx,
+                  "adjacency_bytes": adj_bytes, "all_buffers_bytes": host_bytes,
+                  "round2_same_layer_ms": 39.0,
+                  "note": "round 2 copied every buffer through pageable memory on every AP_START: 39 ms for this layer"}))

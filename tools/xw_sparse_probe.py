@@ -56,6 +56,16 @@ if os.environ.get("SGX_PROBE_ONLY"):                    # under rocprofv3 --pmc:
     torch.cuda.synchronize()
     print(json.dumps(rec), flush=True)
     sys.exit(0)
+if os.environ.get("SGX_PROBE_QUICK"):                   # tools/sweep_xw_sparse.py: the LDS form only, and that it equals the gather form
+    rec["ms_lds"] = [[round(v, 4) for v in timed()] for _ in range(2)]
+    run()
+    H_lds = H.clone()
+    os.environ["SGX_XW_SPARSE_NO_LDS"] = "1"
+    _lib.lib.sgx_reload_env()
+    run()
+    rec["lds_equal_to_gather"] = bool(torch.equal(H_lds, H))
+    print(json.dumps(rec), flush=True)
+    sys.exit(0)
 # the LDS-resident weight slice (default for a matrix this size) against the gather kernel, interleaved in one process
 for rnd in range(3):
     rec.setdefault("ms_lds", []).append([round(v, 4) for v in timed()])
