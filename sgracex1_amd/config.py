@@ -56,6 +56,15 @@ def reference_board_defaults(w_qbits_value=8):
     g.update(acc=1, accb=0, fake_quantization=1, hardware_quantize=1, w_qbits=w_qbits_value, float_type=_np.float32)
 
 
+def snapshot():
+    """every flag's current value (for code that changes flags for a while: `saved = config.snapshot()` ... `config.restore(saved)`)"""
+    return {name: globals()[name] for name in _FLAGS}
+
+
+def restore(saved):
+    globals().update(saved)
+
+
 def describe():
     """name -> (current value, meaning), for notebooks that want to print the configuration."""
     return {name: (globals()[name], doc) for name, (_d, doc) in _FLAGS.items()}

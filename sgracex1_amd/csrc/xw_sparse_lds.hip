@@ -43,6 +43,10 @@ constexpr int kThreads = kWaves * 64;
 #ifndef SGX_XW_LDS_SKIP_UNUSED
 #define SGX_XW_LDS_SKIP_UNUSED 1
 #endif
+#ifndef SGX_XW_LDS_PAIRS
+#define SGX_XW_LDS_PAIRS 0          // 1: entries requested two per lane and instruction (half the vector-memory instructions;
+                                    // measured: the same time, 4 more registers -- tools/sweep_xw_sparse.py)
+#endif
 // an offset that stays out of range after a step's immediate offset (< 4 KiB) is added to it, for the column indices
 // (nnz x 4 bytes) and, halved, for fp16 values (nnz x 2 bytes): the LDS form takes matrices below 2^30 - 2^16 entries
 constexpr unsigned kFarOOB = 0xFFFF0000u;
@@ -147,9 +151,18 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
         int e0, e1;
         int pad_;
     };
+    // PAIRS: a lane requests TWO consecutive entries per instruction (8 bytes of column indices; 8 bytes around its two
+    // values) -- lane i of a quad the entries 2 i, 2 i + 1 of every group of 8, i.e. of two steps -- instead of one entry
+    // per step: half the vector-memory instructions for the same bytes.  The texture-address unit looks every lane of
+    // such an instruction up in the cache, 16 different rows' lines per instruction, and was 67 % busy with one entry
+    // per lane; that, not the vector ALU, is what the stage waits for.
+    constexpr bool PAIRS = SGX_XW_LDS_PAIRS && EPS == 4 && D % 2 == 0;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     struct Entries {                    // ring of D steps: the (column, value) this lane loaded for each
-        unsigned c[D];
-        T a[D];
+        unsigned c[PAIRS ? 1 : D];
+        T a[PAIRS ? 1 : D];
+        u32x2 c2[PAIRS ? D / 2 : 1];    // PAIRS: the two column indices; the two values (fp16: the 8 aligned bytes around them)
+        u32x2 a2[PAIRS ? D / 2 : 1];
     };
 
     // Loads without divergent branches (a conditional load makes hipcc wait for it at the join, which would
@@ -157,8 +170,10 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     // run on past the end of the row (into the next rows' entries; past the end of the arrays the range check
     // returns 0); the select to the zero row of the LDS tile and to a zero value happens when a slot is USED.
     const __amdgpu_buffer_rsrc_t col_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(col), 0, nnz_bytes_col, 0x00020000);
+    // (fp16 values are requested as whole dwords, and the range check drops a dword that straddles the end: the
+    // records are rounded up to whole dwords -- the half behind an odd count lies in the same dword, hence the same page)
     const __amdgpu_buffer_rsrc_t val_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(val), 0, (unsigned)(nnz_bytes_col / 4 * sizeof(T)), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(val), 0, ((unsigned)(nnz_bytes_col / 4 * sizeof(T)) + 3u) & ~3u, 0x00020000);
     const unsigned h_pitch_bytes = (unsigned)ldh * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t h_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(H, 0, (unsigned)((int64_t)(n_rows - 1) * ldh * (int64_t)sizeof(T)) + (unsigned)n_feat * (unsigned)sizeof(T), 0x00020000);
@@ -201,6 +216,21 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
     // issued, from ONE base offset with the step as the instruction's immediate offset -- no per-step address or
     // range arithmetic; slots past the end of the row are dealt with when they are used.
     auto issue_entries = [&](const Meta &m, int k, int nsteps, Entries &en) {
+        if constexpr (PAIRS) {
+            const int e = m.e0 + k * (D * EPS) + 2 * esub;            // this lane's first entry of the unit
+            const unsigned cbase = (unsigned)e * 4u;
+            // fp16 values: the 8 aligned bytes that hold halves e and e + 1 (a 4-byte load wants dword alignment; the
+            // pair is shifted into place when it is used); fp32 values lie like the column indices
+            const unsigned abase = sizeof(T) == 2 ? (unsigned)(e >> 1) * 4u : cbase;
+#pragma unroll
+            for (int j = 0; j < D / 2; ++j) {
+                // (the lanes whose pair belongs to a step behind the sub-tile's last one go out of range: issued, not looked up)
+                const bool wanted = !SGX_XW_LDS_SKIP_UNUSED || k * D + 2 * j + (esub >> 1) < nsteps;
+                en.c2[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(col_rsrc, (wanted ? cbase : kFarOOB) + (unsigned)(j * 32), 0, 0));
+                en.a2[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(val_rsrc, (wanted ? abase : kFarOOB) + (unsigned)(j * (sizeof(T) == 2 ? 16 : 32)), 0, 0));
+            }
+            return;
+        }
         const unsigned base = (unsigned)(m.e0 + k * (D * EPS) + esub) * 4u;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -239,7 +269,49 @@ __global__ __launch_bounds__(kThreads) void xw_sparse_lds_kernel(
         auto lds_read = [&](u32x4 &dst, unsigned byte_off) {
             asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(lds_base + byte_off) : "memory");
         };
+        // PAIRS: what this lane's two entries of the current step pair become (LDS row offsets, fp32 values)
+        unsigned pr_rr[2] = {0u, 0u}, pr_a[2] = {0u, 0u};
+        const int remp = cur.e1 - cur.e0 - k * (D * EPS) - 2 * esub;
+        const unsigned half_shift = (unsigned)((cur.e0 + k * (D * EPS) + 2 * esub) & 1) * 16u;
         auto prep = [&](int d, u32x4 (&raw)[EPS], float (&aa)[EPS]) {
+            if constexpr (PAIRS) {
+                const int j = d >> 1;
+                if ((d & 1) == 0) {
+                    const bool ok0 = remp > 8 * j, ok1 = remp > 8 * j + 1;
+                    pr_rr[0] = (ok0 ? en.c2[j][0] : zero_col) * ROWB;
+                    pr_rr[1] = (ok1 ? en.c2[j][1] : zero_col) * ROWB;
+                    if constexpr (sizeof(T) == 2) {
+                        const unsigned w = __builtin_amdgcn_alignbit(en.a2[j][1], en.a2[j][0], half_shift);    // halves e, e + 1
+                        const f16 h0 = __builtin_bit_cast(f16, (unsigned short)(w & 0xFFFFu)), h1 = __builtin_bit_cast(f16, (unsigned short)(w >> 16));
+                        pr_a[0] = __builtin_bit_cast(unsigned, ok0 ? (float)h0 : 0.0f);
+                        pr_a[1] = __builtin_bit_cast(unsigned, ok1 ? (float)h1 : 0.0f);
+                    } else {
+                        pr_a[0] = ok0 ? en.a2[j][0] : 0u;
+                        pr_a[1] = ok1 ? en.a2[j][1] : 0u;
+                    }
+                }
+                // step d sums entries 4 d .. 4 d + 3 of the unit: the pairs of lanes 2 (d & 1) and 2 (d & 1) + 1 of the quad
+                if ((d & 1) == 0) {
+                    lds_read(raw[0], step_bcast<4, 0>(pr_rr[0]) + my_off);
+                    lds_read(raw[1], step_bcast<4, 0>(pr_rr[1]) + my_off);
+                    lds_read(raw[2], step_bcast<4, 1>(pr_rr[0]) + my_off);
+                    lds_read(raw[3], step_bcast<4, 1>(pr_rr[1]) + my_off);
+                    aa[0] = __builtin_bit_cast(float, step_bcast<4, 0>(pr_a[0]));
+                    aa[1] = __builtin_bit_cast(float, step_bcast<4, 0>(pr_a[1]));
+                    aa[2] = __builtin_bit_cast(float, step_bcast<4, 1>(pr_a[0]));
+                    aa[3] = __builtin_bit_cast(float, step_bcast<4, 1>(pr_a[1]));
+                } else {
+                    lds_read(raw[0], step_bcast<4, 2>(pr_rr[0]) + my_off);
+                    lds_read(raw[1], step_bcast<4, 2>(pr_rr[1]) + my_off);
+                    lds_read(raw[2], step_bcast<4, 3>(pr_rr[0]) + my_off);
+                    lds_read(raw[3], step_bcast<4, 3>(pr_rr[1]) + my_off);
+                    aa[0] = __builtin_bit_cast(float, step_bcast<4, 2>(pr_a[0]));
+                    aa[1] = __builtin_bit_cast(float, step_bcast<4, 2>(pr_a[1]));
+                    aa[2] = __builtin_bit_cast(float, step_bcast<4, 3>(pr_a[0]));
+                    aa[3] = __builtin_bit_cast(float, step_bcast<4, 3>(pr_a[1]));
+                }
+                return;
+            }
             // a slot past the end of the row holds another row's entry (or 0 past the arrays): the zero row of the
             // tile and a zero value, so that a non-finite neighbour never leaks
             const bool ok = rem > d * EPS;

@@ -303,7 +303,7 @@ def test_sgrace_demo_model_trains_on_the_kernels(attention, qbits, floor):
     spec = importlib.util.spec_from_file_location("sgrace_nc", os.path.join(ROOT, "examples", "sgrace_node_classification.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    old = (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type, config.device)
+    old = config.snapshot()
     try:
         res, model, (x, ei, _y) = mod.run(attention, qbits, epochs=60, acc=1, n=2000, verbose=False)
         assert res["test_acc"] > floor, res
@@ -322,8 +322,7 @@ def test_sgrace_demo_model_trains_on_the_kernels(attention, qbits, floor):
         assert close.float().mean() > (0.999 if qbits == 32 else 0.97), float((on_gpu - on_cpu).abs().max())
         assert (on_gpu.argmax(1) == on_cpu.argmax(1)).float().mean() > 0.98
     finally:
-        (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type,
-         config.device) = old
+        config.restore(old)
         sgrace.init_SGRACE()
 
 

@@ -146,7 +146,7 @@ def test_sgrace_layers_quantised_on_the_gpu_match_the_dense_twin(bits, gat):
     _, _, w2, att2 = _graph_case(300, 16, 16, 78 + bits)
     idx = adj.nonzero().t()
     norm = adj[idx[0], idx[1]]
-    old = (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type, config.device)
+    old = config.snapshot()
     outs = {}
     try:
         for acc in (0, 1):
@@ -168,8 +168,7 @@ def test_sgrace_layers_quantised_on_the_gpu_match_the_dense_twin(bits, gat):
         assert close.float().mean() > 0.99, float((outs[1][0] - outs[0][0]).abs().max())
         assert bits == 1 or outs[0][0].abs().max() > 0     # one bit: layer-2 inputs below 0.5 quantise to 0
     finally:
-        (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type,
-         config.device) = old
+        config.restore(old)
         sgrace.init_SGRACE()
 
 
@@ -322,8 +321,7 @@ def test_hardware_quantize_reaches_the_int8_matrix_cores_through_the_library_lay
         return real(*a, **kw)
 
     monkeypatch.setattr(ops, "layer_forward", spy)
-    old = (config.acc, config.fake_quantization, config.hardware_quantize, config.w_qbits, config.compute_attention,
-           config.float_type, config.device)
+    old = config.snapshot()
     outs = {}
     try:
         for hw in (0, 1):
@@ -341,6 +339,5 @@ def test_hardware_quantize_reaches_the_int8_matrix_cores_through_the_library_lay
         assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
         assert outs[1][0].abs().max() > 0
     finally:
-        (config.acc, config.fake_quantization, config.hardware_quantize, config.w_qbits, config.compute_attention,
-         config.float_type, config.device) = old
+        config.restore(old)
         sgrace.init_SGRACE()

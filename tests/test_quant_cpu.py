@@ -65,7 +65,7 @@ def test_dense_twin_equals_the_restatement(bits, gat):
     adj, x, w, att = _case(40, 23, 8, 5 + bits)
     c = quant.constants(bits)
     want, _e, _p, _wh = QO.layer(adj, x, w, att, c, relu=1, compute_attention=gat)
-    old = (config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type)
+    old = config.snapshot()
     try:
         config.acc, config.fake_quantization, config.w_qbits, config.compute_attention = 0, 1, bits, gat
         config.float_type = np.float32
@@ -82,7 +82,7 @@ def test_dense_twin_equals_the_restatement(bits, gat):
         got.sum().backward()
         assert layer.weight.grad is not None and torch.isfinite(layer.weight.grad).all()
     finally:
-        config.acc, config.fake_quantization, config.w_qbits, config.compute_attention, config.float_type = old
+        config.restore(old)
         sgrace.init_SGRACE()
 
 

@@ -253,8 +253,23 @@ def main():
                 lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, **kw), 50)
             rec[f"ms_layer_fp32_{name}_8bit_int8_operands"] = timed(
                 lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, quant_int8=True, **kw), 50)
+            # what config.hardware_quantize = 1 runs (SGX_QUANT_INT8_AUTO): the faster of the two forms by shape
+            rec[f"ms_layer_fp32_{name}_8bit_hardware_quantize"] = timed(
+                lambda: ops.layer_forward(A32, X32, Wt32, relu=True, out=D32, quant=qc, quant_int8="auto", **kw), 50)
         report("c5 in the SGRACE library's setting (float32 buffers, w_qbits 8)", A32, rec, {"f_in": 128, "width": P})
-        del A32, X32, D32
+        # the same graph with Reddit's 602 input features (a dense-feature layer wider than 128 columns: the shape the
+        # integer operands are chosen for), 602 -> 128
+        X602 = torch.rand((n, 602), generator=gen, device=dev)
+        Wt602 = (torch.rand((128, 602), generator=gen, device=dev) * 2 - 1) / 128 ** 0.5
+        D128 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        rec = {"ms_layer_fp32_gcn": timed(lambda: ops.layer_forward(A32, X602, Wt602, relu=True, out=D128), 30),
+               "ms_layer_fp32_gcn_8bit_quantised": timed(lambda: ops.layer_forward(A32, X602, Wt602, relu=True, out=D128, quant=qc), 30),
+               "ms_layer_fp32_gcn_8bit_int8_operands": timed(
+                   lambda: ops.layer_forward(A32, X602, Wt602, relu=True, out=D128, quant=qc, quant_int8=True), 30),
+               "ms_layer_fp32_gcn_8bit_hardware_quantize": timed(
+                   lambda: ops.layer_forward(A32, X602, Wt602, relu=True, out=D128, quant=qc, quant_int8="auto"), 30)}
+        report("arxiv-sized graph, 602 dense input features -> 128, float32 buffers, w_qbits 8", A32, rec, {"f_in": 602, "width": 128})
+        del A32, X32, D32, X602, D128
         # the X.W stage of a quantised layer alone on the Reddit shape (232 965 x 602 -> 128): fp32 values on the 8-bit
         # grid through the fp32 MFMA kernel against integer codes through the int8 matrix cores, with and without the
         # pass that quantises X (a caller that keeps its features as codes skips it)

@@ -16,11 +16,11 @@ CSRC = os.path.join(ROOT, "sgracex1_amd", "csrc")
 OUT = os.path.join(ROOT, "_variants")
 
 VARIANTS = {
-    "skip1_d8": dict(SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=8),
-    "skip0_d8": dict(SGX_XW_LDS_SKIP_UNUSED=0, SGX_XW_LDS_DEPTH=8),
-    "skip1_d6": dict(SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=6),
-    "skip1_d7": dict(SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=7),
-    "skip1_d10": dict(SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=10),
+    "pairs1_skip1_d8": dict(SGX_XW_LDS_PAIRS=1, SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=8),
+    "pairs0_skip1_d8": dict(SGX_XW_LDS_PAIRS=0, SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=8),
+    "pairs1_skip0_d8": dict(SGX_XW_LDS_PAIRS=1, SGX_XW_LDS_SKIP_UNUSED=0, SGX_XW_LDS_DEPTH=8),
+    "pairs1_skip1_d6": dict(SGX_XW_LDS_PAIRS=1, SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=6),
+    "pairs1_skip1_d10": dict(SGX_XW_LDS_PAIRS=1, SGX_XW_LDS_SKIP_UNUSED=1, SGX_XW_LDS_DEPTH=10),
 }
 
 
