@@ -28,7 +28,15 @@ def load(pattern):
 
 
 def counter(rows, kernel_sub, name):
-    return [float(r["Counter_Value"]) for r in rows if kernel_sub in r["Kernel_Name"] and r["Counter_Name"] == name]
+    subs = kernel_sub if isinstance(kernel_sub, tuple) else (kernel_sub,)
+    return [float(r["Counter_Value"]) for r in rows if any(s in r["Kernel_Name"] for s in subs) and r["Counter_Name"] == name]
+
+
+def agg_kernels(wl):
+    """the A.H launch of a workload in a trace: the plain kernel on the uniform graph; under a degree-ordered plan
+    (power-law graphs) the kernel with the one-step tail.  (The default bench line also times the R-MAT leg, so a
+    trace of the s100m workload holds both; each summary takes its own.)"""
+    return ("spmm_short_tail_kernel",) if "rmat" in wl else ("11spmm_kernelI",)
 
 
 def main():
@@ -50,20 +58,21 @@ def main():
     # per-dispatch durations of the aggregation kernel: the A.H launches are the long ones
     trace = load(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace
-                  if "spmm_kernel" in r["Kernel_Name"])
+                  if any(k in r["Kernel_Name"] for k in agg_kernels(wl)))
     big = [d for d in durs if d > 0.6 * durs[-1]] if durs else []
     bench_line = None
     for ln in open(os.path.join(src, "bench_trace.log")):
         if ln.startswith("{"):
             bench_line = json.loads(ln)
 
-    K = "spmm_kernel"
+    K = agg_kernels(wl)
     fetch = counter(load(os.path.join(src, "pmc_fetch", "*", "*_counter_collection.csv")), K, "FETCH_SIZE")
     write = counter(load(os.path.join(src, "pmc_write", "*", "*_counter_collection.csv")), K, "WRITE_SIZE")
     l2 = load(os.path.join(src, "pmc_l2", "*", "*_counter_collection.csv"))
     hit, miss = counter(l2, K, "TCC_HIT_sum"), counter(l2, K, "TCC_MISS_sum")
-    cal_f = counter(load(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")), K, "FETCH_SIZE")
-    cal_w = counter(load(os.path.join(src, "cal_write", "*", "*_counter_collection.csv")), K, "WRITE_SIZE")
+    KC = ("11spmm_kernelI", "spmm_short_tail_kernel")           # the calibration launches (tools/pmc_calibrate.py): whichever form ran
+    cal_f = counter(load(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")), KC, "FETCH_SIZE")
+    cal_w = counter(load(os.path.join(src, "cal_write", "*", "*_counter_collection.csv")), KC, "WRITE_SIZE")
     cal_copy = counter(load(os.path.join(src, "cal_fetch", "*", "*_counter_collection.csv")), "copyBuffer", "FETCH_SIZE")
 
     rl = bench_line["roofline"]
@@ -81,7 +90,9 @@ def main():
     n_cal = 1 << 24
     cal_true = n_cal * 128 + n_cal * 6 + (n_cal + 1) * 4
     summary = {
-        "workload": wl, "tag": tag, "kernel": "spmm_kernel<f16,8,8> (A.H launches)",
+        "workload": wl, "tag": tag,
+        "kernel": ("spmm_short_tail_kernel<f16,8,8> (A.H launches: sblock rows + the one-step tail, 64 rows per wavefront)"
+                   if "rmat" in wl else "spmm_kernel<f16,8,8> (A.H launches)"),
         "launch_ns_kernel_trace": {"avg": sum(big) / len(big), "min": big[0], "max": big[-1], "n": len(big)},
         "launch_ms_bench_events": {"avg": rl["avg_launch_ms"], "min": rl["min_launch_ms"]},
         "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
@@ -117,7 +128,8 @@ def main():
     summary["other_kernels_raw_counters"] = others
     with open(os.path.join(out, f"{tag}_{wl}_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    with open(os.path.join(out, "traffic_latest.json"), "w") as f:
+    # what bench.py quotes as roofline.traffic (s100m) / roofline_rmat.traffic (s100m-rmat)
+    with open(os.path.join(out, "traffic_latest.json" if wl == "s100m" else f"traffic_{wl}.json"), "w") as f:
         json.dump({"workload": wl, "tag": tag, "hbm_bytes_per_launch": read_bytes + write_bytes,
                    "source": f"profiles/{tag}_{wl}_pmc.json"}, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k not in ("bench_line",)}, indent=1))
