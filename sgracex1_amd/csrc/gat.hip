@@ -801,6 +801,8 @@ __device__ __forceinline__ void alpha_row_in_registers(
     l_out = l;
 }
 
+// (Round 3 tried the several-heads kernel's split here too -- the rows of up to 64 edges in one launch, the longer ones dealt
+// out cyclically in a second -- and measured nothing: 1.026 against 1.009 ms on a 29 M-edge R-MAT graph; one launch stays.)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gat_alpha_rows_1head_kernel(
     int n_rows, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const T *__restrict__ val,
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_1head_kernel(
     const int lane = threadIdx.x & 63, sub = lane % GL, grp = lane / GL;
     const int64_t r_first = ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * (64 / GL);
     const int64_t r = r_first + grp;
+    auto row_of = [&](int g) -> int64_t { return r_first + g; };
     int e0 = 0, e1 = 0;
     if (r < n_rows) { e0 = rowptr[r]; e1 = rowptr[r + 1]; }
     const bool tasked = long_threshold > 0 && e1 - e0 > long_threshold;           // the tasks own it
@@ -843,16 +846,16 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_1head_kernel(
         if (dg == 0) continue;                                                     // wave-uniform
         const int ge0 = __shfl(e0, g * GL);
         float l = 0.0f;
-        alpha_row_in_registers<T, 64>(true, ge0, dg, lane, (dg + 63) / 64, s1[r_first + g], alpha, col_rsrc, val_rsrc, s2_rsrc, w_rsrc,
+        alpha_row_in_registers<T, 64>(true, ge0, dg, lane, (dg + 63) / 64, s1[row_of(g)], alpha, col_rsrc, val_rsrc, s2_rsrc, w_rsrc,
                                       e_rsrc, E != nullptr, l);
-        if (lane == 0) dead[r_first + g] = l > 0.0f ? 0 : 1;
+        if (lane == 0) dead[row_of(g)] = l > 0.0f ? 0 : 1;
     }
     // rows over 512 edges that the plan did not cut: two walks over memory, whole wavefront
     for (int g = 0; g < 64 / GL; ++g) {
         const int dg = __shfl(big_deg, g * GL);
         if (dg == 0) continue;
         const int ge0 = __shfl(e0, g * GL), ge1 = ge0 + dg;
-        const int64_t gr = r_first + g;
+        const int64_t gr = row_of(g);
         const float si = s1[gr];
         float m = -INFINITY, l = 0.0f;
         for (int idx = ge0 + lane; idx < ge1; idx += 64) {
@@ -1260,34 +1263,50 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_task_stats_kernel(
     }
 }
 
-// long rows, step 2: the tasks of a row merged in task order
+// long rows, step 2: the tasks of a row merged in task order (eight states requested at a time), and the row's state
+// written back over every one of its tasks' states, so that step 3 can run per TASK and read pm / pl at its own index
 __global__ __launch_bounds__(kBlock) void gat_alpha_long_merge_kernel(
     int n_long, int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
-    const float *__restrict__ pm, const float *__restrict__ pl, float *__restrict__ row_m, float *__restrict__ row_l,
+    float *__restrict__ pm, float *__restrict__ pl, float *__restrict__ row_m, float *__restrict__ row_l,
     unsigned char *__restrict__ dead)
 {
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= (int64_t)n_long * n_heads) return;
     const int i = (int)(gid / n_heads), h = (int)(gid % n_heads);
     float m = -INFINITY, l = 0.0f;
-    for (int t = long_first[i]; t < long_first[i + 1]; ++t) softmax_merge(m, l, pm[(int64_t)t * n_heads + h], pl[(int64_t)t * n_heads + h]);
+    const int t0 = long_first[i], t_end = long_first[i + 1];
+    int t = t0;
+    for (; t + 8 <= t_end; t += 8) {
+        float vm[8], vl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { vm[u] = pm[(int64_t)(t + u) * n_heads + h]; vl[u] = pl[(int64_t)(t + u) * n_heads + h]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) softmax_merge(m, l, vm[u], vl[u]);
+    }
+    for (; t < t_end; ++t) softmax_merge(m, l, pm[(int64_t)t * n_heads + h], pl[(int64_t)t * n_heads + h]);
     row_m[gid] = m;
     row_l[gid] = l;
+    for (t = t0; t < t_end; ++t) { pm[(int64_t)t * n_heads + h] = m; pl[(int64_t)t * n_heads + h] = l; }
     if (h == 0) dead[long_row[i]] = l > 0.0f ? 0 : 1;
 }
 
-// long rows, step 3: the weights of their edges (workgroup (i, y) walks every gridDim.y-th 256-edge piece of long row i)
+// long rows, step 3: the weights of their edges, one wavefront per TASK (round 2 gave every long row 16 workgroups
+// whatever its length -- 347 K workgroups for the 21.7 K long rows of a 29 M-edge R-MAT graph, most of them idle: 148 us;
+// the row's merged state lies at the task's own index after step 2)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
-    int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-    const T *__restrict__ val, const float *__restrict__ s1, const float *__restrict__ s2, float alpha,
-    const float *__restrict__ row_m, const float *__restrict__ row_l, float *__restrict__ W)
+    int n_tasks, int n_heads, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
+    const int32_t *__restrict__ task_e1, const int32_t *__restrict__ col, const T *__restrict__ val,
+    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, const float *__restrict__ pm,
+    const float *__restrict__ pl, float *__restrict__ W)
 {
-    const int i = blockIdx.x;
-    const int64_t row = long_row[i];
-    const int e1 = rowptr[row + 1];
+    const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (task >= n_tasks) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = task_row[task];
+    const int te0 = task_e0[task], te1 = task_e1[task];
     const bool vec8 = n_heads % 8 == 0 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(W)) % 16 == 0;
-    for (int idx = rowptr[row] + blockIdx.y * kBlock + threadIdx.x; idx < e1; idx += gridDim.y * kBlock) {
+    for (int idx = te0 + lane; idx < te1; idx += 64) {
         const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
         const int c = col[idx];
         for (int hb0 = 0; hb0 < n_heads; hb0 += 8) {
@@ -1297,7 +1316,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
             for (int k = 0; k < 8; ++k) {
                 float w = 0.0f;
                 if (hb0 + k < n_heads) {
-                    const float m = row_m[(int64_t)i * n_heads + hb0 + k], l = row_l[(int64_t)i * n_heads + hb0 + k];
+                    const float m = pm[(int64_t)task * n_heads + hb0 + k], l = pl[(int64_t)task * n_heads + hb0 + k];
                     if (pos && l > 0.0f) w = expf(leaky(s1[row * n_heads + hb0 + k] + sc[k], alpha) - m) / l;
                 }
                 sc[k] = w;
@@ -1311,13 +1330,16 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
 // tasks (all lane groups of a wavefront on one task, fp32 partial rows), the others one row per lane group.  HEADS = 0:
 // one weight per edge, loaded with the column by the edge's lane and shuffled; HEADS = 1: every lane loads the weight
 // of its own head for each edge through a buffer resource (out of range past the row's end: 0, no access).
-template <typename T, int VEC, int LPR, int HEADS>
+// SHORT: the degree order's tail of one-step rows (at most 8 edges) 64 rows per wavefront, as spmm_short_rows does for the
+// plain aggregation (spmm_csr.hip: every link of row id -> row pointers -> (column, weight) -> gather is one round trip
+// for 64 rows; the same fma chain per output element, hence the same bits); workgroups from short_first on.
+template <typename T, int VEC, int LPR, int HEADS, bool SHORT>
 __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
     int n_work, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const float *__restrict__ W, unsigned w_bytes, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     T *__restrict__ D, int64_t ldd, int relu, float out_scale, int long_threshold, int vec_store,
     const int32_t *__restrict__ row_order, int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0,
-    const int32_t *__restrict__ task_e1, float *__restrict__ partial, int ldp)
+    const int32_t *__restrict__ task_e1, float *__restrict__ partial, int ldp, int n_multi, int short_first)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -1388,8 +1410,73 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
         }
         return;
     }
+    if constexpr (SHORT && LPR >= 8) {
+        if ((int)blockIdx.x >= short_first) {
+            constexpr int ITER = LPR;
+            const int64_t i0 = (int64_t)n_multi + ((int64_t)((int)blockIdx.x - short_first) * (kBlock / 64) + (threadIdx.x >> 6)) * 64;
+            if (i0 >= n_work) return;
+            const int64_t idx = i0 + lane;
+            const bool valid = idx < n_work;
+            const int rid = row_order[valid ? idx : (int64_t)n_work - 1];
+            const int re0 = rowptr[rid];
+            const int rdeg = valid ? rowptr[rid + 1] - re0 : 0;              // at most 8 (the order's last buckets)
+            constexpr int CH = 8;                        // iterations per batch of (column, weight) requests
+            const int col0 = sub * VEC;
+            const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+            const unsigned my_head = HEADS ? (unsigned)((col0 < n_feat ? col0 : 0) / f_head) : 0u;
+            for (int it0 = 0; it0 < ITER; it0 += CH) {
+            unsigned c[CH];
+            float a[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int s = (it0 + i) * RPW + grp;
+                const int se0 = __shfl(re0, s), sdeg = __shfl(rdeg, s);
+                const int e = sub < sdeg ? se0 + sub : 0;                    // (unconditional loads: slots past the row read entry 0, masked at use)
+                c[i] = (unsigned)__builtin_nontemporal_load(col + e);
+                a[i] = HEADS ? 0.0f : __builtin_nontemporal_load(W + e);
+            }
+#pragma unroll
+            for (int it = 0; it < CH; ++it) {
+                const int s = (it0 + it) * RPW + grp;
+                const int se0 = __shfl(re0, s), sdeg = __shfl(rdeg, s);
+                const int64_t rr = __shfl(rid, s);
+                const bool live = __shfl((int)valid, s) != 0;
+                float acc[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const unsigned cc = (unsigned)__shfl((int)c[it], t, LPR);
+                    float aa;
+                    if (HEADS)
+                        aa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                 wsrc, t < sdeg ? ((unsigned)(se0 + t) * (unsigned)n_heads + my_head) * 4u : kOOB, 0, 0));
+                    else
+                        aa = __shfl(a[it], t, LPR);
+                    Gather<T, VEC>::run(acc, aa, rsrc, (t < sdeg && col_off != kOOB) ? cc * ld_bytes + col_off : kOOB);
+                }
+                if (live && col0 < n_feat) {
+                    T out[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) out[i] = gat_finish<T>(acc[i], relu, out_scale);
+                    T *drow = D + rr * ldd;
+                    if (VEC > 1 && vec_store && col0 + VEC <= n_feat) {
+                        *reinterpret_cast<u32x4 *>(drow + col0) = *reinterpret_cast<const u32x4 *>(out);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            if (col0 + i < n_feat) drow[col0 + i] = out[i];
+                    }
+                }
+            }
+            }
+            return;
+        }
+        n_work = n_multi;                    // the walk below takes the rows of two steps and more
+    }
+    const int row_grid = (SHORT ? short_first : (int)gridDim.x) - split_blocks;
     const int64_t wave = (int64_t)(blockIdx.x - split_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)(gridDim.x - split_blocks) * (kBlock / 64);
+    const int64_t n_waves = (int64_t)row_grid * (kBlock / 64);
     for (int64_t r0 = wave * RPW; r0 < n_work; r0 += n_waves * RPW) {
         int64_t r = r0 + grp;
         int e0 = 0, e1 = 0;
@@ -1433,7 +1520,18 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_finalize_kernel(
     if (gid >= (int64_t)n_long * n_feat) return;
     const int l = (int)(gid / n_feat), j = (int)(gid % n_feat);
     float s = 0.0f;
-    for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
+    // task order, eight loads in flight at a time (the GAT plan cuts at 256 edges: a hub row of a power-law graph has
+    // hundreds of tasks, and one dependent load after the other made this kernel 89 us on a 29 M-edge graph)
+    const int t_end = long_first[l + 1];
+    int t = long_first[l];
+    for (; t + 8 <= t_end; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(t + u) * ldp + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; t < t_end; ++t) s += partial[(int64_t)t * ldp + j];
     D[(int64_t)long_row[l] * ldd + j] = gat_finish<T>(s, relu, out_scale);
 }
 
@@ -1460,9 +1558,9 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
     const int thr = p->n_long > 0 ? p->long_threshold : 0;
     const int rows_per_block = (64 / kAlphaLanes) * (kBlock / 64);
     if (a.n_heads == 1) {
-        hipLaunchKernelGGL((gat_alpha_rows_1head_kernel<T>), dim3((unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block)),
-                           dim3(kBlock), 0, a.stream, a.n_rows, a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,
-                           (unsigned)((size_t)a.n_cols * 4), a.alpha, thr, W, a.E, dead);
+        const dim3 grid1((unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block));
+        hipLaunchKernelGGL((gat_alpha_rows_1head_kernel<T>), grid1, dim3(kBlock), 0, a.stream, a.n_rows, a.rowptr, a.col,
+                           (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2, (unsigned)((size_t)a.n_cols * 4), a.alpha, thr, W, a.E, dead);
     } else if (a.n_heads <= 64) {
         int lh = sgx_next_pow2(a.n_heads);
         const int rpb = (64 / lh) * (kBlock / 64);
@@ -1472,9 +1570,10 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
         hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L, 1>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads,      \
                            a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                \
                            (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                        \
-        hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L, 2>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads,      \
-                           a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                                \
-                           (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                        \
+        if (p->max_degree > kAloneEdges) /* (the second launch serves only rows above that: none on e.g. a uniform graph) */ \
+            hipLaunchKernelGGL((gat_alpha_rows_heads_kernel<T, L, 2>), grid, dim3(kBlock), 0, a.stream, a.n_rows, a.n_heads,  \
+                               a.rowptr, a.col, (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2,                            \
+                               (unsigned)((size_t)a.n_cols * a.n_heads * 4), a.alpha, thr, W, a.E, dead);                    \
         break;
         switch (lh) {
             SGX_GAT_LH(2) SGX_GAT_LH(4) SGX_GAT_LH(8) SGX_GAT_LH(16) SGX_GAT_LH(32) SGX_GAT_LH(64)
@@ -1495,8 +1594,9 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
         hipLaunchKernelGGL(gat_alpha_long_merge_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream,
                            p->n_long, a.n_heads, p->long_row, p->long_first, pm, pl, row_m, row_l, dead);
         SGX_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_alpha_long_write_kernel<T>), dim3(p->n_long, 16), dim3(kBlock), 0, a.stream, a.n_heads,
-                           p->long_row, a.rowptr, a.col, (const T *)a.val, s1, s2, a.alpha, row_m, row_l, W);
+        hipLaunchKernelGGL((gat_alpha_long_write_kernel<T>), dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0,
+                           a.stream, p->n_tasks, a.n_heads, p->task_row, p->task_e0, p->task_e1, a.col, (const T *)a.val, s1, s2,
+                           a.alpha, pm, pl, W);
         SGX_LAUNCH_CHECK();
     }
     return SGX_OK;
@@ -1547,19 +1647,29 @@ int gat_two_stage(const GatArgs &a)
     const int n_work = order ? p->n_ordered : a.n_rows;
     const int n_tasks = thr > 0 ? p->n_tasks : 0;
     const int split_blocks = (n_tasks + kBlock / 64 - 1) / (kBlock / 64);
-    int64_t row_blocks = ((int64_t)n_work + rows_per_block - 1) / rows_per_block;
+    // the one-step tail of a degree order 64 rows per wavefront (as the plain aggregation does, spmm_csr.hip)
+    const bool short_tail = LPR >= 8 && order && !sgx_tune().spmm_no_short_tail && p->n_multi >= 0 && p->n_multi < n_work &&
+                            a.n_feat <= LPR * VEC && n_work - p->n_multi >= 4096;
+    const int n_multi = short_tail ? p->n_multi : n_work;
+    const int64_t short_blocks = short_tail ? ((int64_t)(n_work - n_multi) + 64 * (kBlock / 64) - 1) / (64 * (kBlock / 64)) : 0;
+    int64_t row_blocks = ((int64_t)n_multi + rows_per_block - 1) / rows_per_block;
     if (row_blocks > 256 * 512) row_blocks = 256 * 512;
     const unsigned w_bytes = (unsigned)((size_t)p->nnz * a.n_heads * sizeof(float));
-    if (a.n_heads > 1)
-        hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, 1>), dim3((unsigned)(split_blocks + row_blocks)), dim3(kBlock), 0,
-                           a.stream, n_work, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes,
-                           a.ld_bytes, (T *)a.D, a.ldd, a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks,
-                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, pacc, ldp);
-    else
-        hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, 0>), dim3((unsigned)(split_blocks + row_blocks)), dim3(kBlock), 0,
-                           a.stream, n_work, a.n_feat, a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes,
-                           a.ld_bytes, (T *)a.D, a.ldd, a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks,
-                           n_tasks ? p->task_e0 : nullptr, n_tasks ? p->task_e1 : nullptr, pacc, ldp);
+    const dim3 grid_b((unsigned)(split_blocks + row_blocks + short_blocks));
+    const int short_first = (int)(split_blocks + row_blocks);
+#define SGX_GAT_WEIGHTED(HEADS_, SHORT_)                                                                                          \
+    hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, HEADS_, SHORT_>), grid_b, dim3(kBlock), 0, a.stream, n_work, a.n_feat,     \
+                       a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes, a.ld_bytes, (T *)a.D, a.ldd,      \
+                       a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks, n_tasks ? p->task_e0 : nullptr,         \
+                       n_tasks ? p->task_e1 : nullptr, pacc, ldp, n_multi, short_first)
+    if (a.n_heads > 1) {
+        if (short_tail) SGX_GAT_WEIGHTED(1, true);
+        else SGX_GAT_WEIGHTED(1, false);
+    } else {
+        if (short_tail) SGX_GAT_WEIGHTED(0, true);
+        else SGX_GAT_WEIGHTED(0, false);
+    }
+#undef SGX_GAT_WEIGHTED
     SGX_LAUNCH_CHECK();
     if (n_tasks > 0) {
         const int64_t total = (int64_t)p->n_long * a.n_feat;

@@ -55,7 +55,7 @@ struct PlanCounts {
     unsigned long long useful;     // lane-group steps that do work, rows packed 8 to a wavefront in natural order
     unsigned long long spent;      // lane-group steps such wavefronts run for
     unsigned n_long, n_tasks;
-    int nnz, long_threshold, chunk, pad;      // the entry count the device read and the cut it picked from it (below)
+    int nnz, long_threshold, chunk, max_degree;      // the entry count the device read, the cut it picked from it (below), the longest row
 };
 
 // The cut depends on the entry count, which lives in HBM (rowPtr[n_rows]): the counting kernel reads it there and picks
@@ -128,12 +128,13 @@ __global__ __launch_bounds__(kThreads) void plan_count_kernel(const int32_t *__r
     __syncthreads();
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r_end = r_begin + rows_per_block < n_rows ? r_begin + rows_per_block : (int64_t)n_rows;
-    int useful = 0, spent = 0, n_long = 0, n_tasks = 0;
+    int useful = 0, spent = 0, n_long = 0, n_tasks = 0, max_deg = 0;
     for (int64_t base = r_begin; base < r_end; base += kThreads) {
         const int64_t r = base + threadIdx.x;
         const bool valid = r < r_end;
         const int deg = valid ? rowptr[r + 1] - rowptr[r] : 0;
         const bool is_long = deg > long_threshold;
+        max_deg = max(max_deg, deg);
         const int steps = is_long ? 0 : (deg + 7) / 8;
         int mx = steps;                            // the longest of the 8 rows a wavefront would pack with this one
         mx = max(mx, __shfl_xor(mx, 1));
@@ -156,7 +157,10 @@ __global__ __launch_bounds__(kThreads) void plan_count_kernel(const int32_t *__r
     }
     n_long = wave_sum(n_long);
     n_tasks = wave_sum(n_tasks);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_deg = max(max_deg, __shfl_xor(max_deg, o));
     if ((threadIdx.x & 63) == 0) {
+        atomicMax(&totals->max_degree, max_deg);
         atomicAdd(&s_useful, u);
         atomicAdd(&s_spent, s);
         atomicAdd(&s_long, n_long);
@@ -357,6 +361,7 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     p->win_order = nullptr;
     p->n_ordered = 0;
     p->n_multi = -1;
+    p->max_degree = 0;
     p->natural_utilization = 1.0f;
     resolve_cut(0, long_threshold_arg, chunk_arg, tune.plan_long_threshold, tune.plan_chunk, p->long_threshold, p->chunk);
     if (n_blocks == 0) {
@@ -389,6 +394,7 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     p->n_long = (int)host.n_long;
     p->n_tasks = (int)host.n_tasks;
     p->natural_utilization = host.spent > 0 ? (float)((double)host.useful / (double)host.spent) : 1.0f;
+    p->max_degree = host.max_degree;
     bool launched_after_readback = false;
 
     if (p->n_long > 0) {

@@ -67,6 +67,7 @@ struct sgx_plan {
     // matrices that form can take (2^20 entries and more, no long rows), NULL otherwise.
     uint8_t *win_order;    // [ceil(n_rows / 64) * 64]
     float natural_utilization;   // share of lane-group steps doing work when rows are packed in natural order
+    int max_degree;              // the longest row (lets a caller skip launches that only serve rows above some length)
 };
 
 // leading dimension (elements) the library uses for its own H = X.W scratch.  Rows are padded to a multiple of

@@ -218,21 +218,24 @@ __device__ __forceinline__ void spmm_short_rows(
     const int deg = valid ? rowptr[r + 1] - e0 : 0;               // at most 8 (the plan's last buckets)
     // the (column, value) pairs of all iterations; unconditional loads (a conditional load makes hipcc wait for it at
     // the join): slots past the end of a row read entry 0 and are masked when they are used
-    unsigned c[ITER];
-    T a[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int s = it * RPW + grp;
-        const int se0 = __shfl(e0, s), sdeg = __shfl(deg, s);
-        const int e = sub < sdeg ? se0 + sub : 0;
-        c[it] = (unsigned)__builtin_nontemporal_load(col + e);
-        a[it] = __builtin_nontemporal_load(val + e);
-    }
+    // (the iterations are taken 8 at a time -- the pairs of one batch are 16 registers -- whatever the lane split)
+    constexpr int CH = 8;
     const int col0 = sub * VEC;
     const unsigned chunk_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
+    for (int it0 = 0; it0 < ITER; it0 += CH) {
+    unsigned c[CH];
+    T a[CH];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int s = it * RPW + grp;
+    for (int i = 0; i < CH; ++i) {
+        const int s = (it0 + i) * RPW + grp;
+        const int se0 = __shfl(e0, s), sdeg = __shfl(deg, s);
+        const int e = sub < sdeg ? se0 + sub : 0;
+        c[i] = (unsigned)__builtin_nontemporal_load(col + e);
+        a[i] = __builtin_nontemporal_load(val + e);
+    }
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+        const int s = (it0 + it) * RPW + grp;
         const int sdeg = __shfl(deg, s);
         const int64_t rr = __shfl(r, s);
         const bool live = __shfl((int)valid, s) != 0;
@@ -258,6 +261,7 @@ __device__ __forceinline__ void spmm_short_rows(
         } else if (live && col0 < n_feat) {
             store_row<T, VEC>(D + rr * ldd, col0, n_feat, acc, relu, vec_store != 0, ep);
         }
+    }
     }
 }
 
@@ -421,7 +425,18 @@ __global__ __launch_bounds__(kBlock) void spmm_split_finalize_kernel(
     const int l = (int)(gid / n_feat), j = (int)(gid % n_feat);
     const int64_t row = long_row[l];
     float s = acc_in ? acc_in[row * ld_acc + j] : 0.0f;
-    for (int t = long_first[l]; t < long_first[l + 1]; ++t) s += partial[(int64_t)t * ldp + j];
+    // the partial rows of a long row are added in task order; eight loads are in flight at a time (a hub row has tens to
+    // hundreds of tasks: one dependent load after the other was a round trip to memory each)
+    const int t_end = long_first[l + 1];
+    int t = long_first[l];
+    for (; t + 8 <= t_end; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(t + u) * ldp + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; t < t_end; ++t) s += partial[(int64_t)t * ldp + j];
     if (acc_out) { acc_out[row * ld_acc + j] = s; return; }
     D[row * ldd + j] = finish_value<T>(s, relu, ep);
 }
