@@ -29,6 +29,7 @@ struct sgx_tuning {
     bool xtg_scalar, xtg_wave_tiles;
     bool spmm_no_short_tail;      // the one-step tail of a degree order through the sblock path (as in round 2)
     int spmm_cpl;                 // 0 = unset
+    int xw_sparse_lpr;            // 0 = unset: lanes per row (slice width / 16 bytes) of the sparse X.W stage's LDS form, at most
     int plan_long_threshold;      // 0 = unset
     int plan_chunk;               // 0 = unset
     float plan_reorder_below;     // < 0 = unset

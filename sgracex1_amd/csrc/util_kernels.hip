@@ -293,6 +293,7 @@ void load_tuning()
     t.xtg_wave_tiles = flag("SGX_XTG_WAVE_TILES");
     t.spmm_no_short_tail = flag("SGX_SPMM_NO_SHORT_TAIL");
     t.spmm_cpl = num("SGX_SPMM_CPL");
+    t.xw_sparse_lpr = num("SGX_XW_SPARSE_LPR");
     t.plan_long_threshold = num("SGX_PLAN_LONG_THRESHOLD");
     t.plan_chunk = num("SGX_PLAN_CHUNK");
     const char *rb = getenv("SGX_PLAN_REORDER_BELOW");

@@ -507,6 +507,7 @@ int choose_lpr(int dtype, int m_fea, int n_feat)
     if (need > 16) need = 16;
     int lpr = need;
     while (lpr >= 1 && (size_t)(m_fea + 1) * lpr * 16 > kLdsBudget) lpr >>= 1;
+    if (sgx_tune().xw_sparse_lpr > 0 && sgx_tune().xw_sparse_lpr < lpr) lpr = sgx_tune().xw_sparse_lpr;      // tuning override: narrower slices
     return lpr >= 2 ? lpr : 0;                                      // 0: not even a 32-byte slice fits (one-lane rows stay with the gather kernel)
 }
 
