@@ -298,8 +298,8 @@ class IP:
         hit = win.mirrors.get(key)
         if hit is not None and hit[0] == stamp:
             if os.environ.get("SGX_SHIM_VERIFY"):
-                ref = torch.from_numpy(np.ascontiguousarray(host if host.dtype in self._TORCH_OF else host.astype(np.int64)))
-                if not torch.equal(hit[1].cpu().to(ref.dtype) if want is None else hit[1].cpu(), ref.to(hit[1].dtype)):
+                now = torch.from_numpy(np.ascontiguousarray(host if host.dtype in self._TORCH_OF else host.astype(np.int64)))
+                if not torch.equal(hit[1].cpu(), now.to(hit[1].dtype)):
                     raise RuntimeError(f"{reg}: the device mirror is stale although write counter and content stamp match "
                                        "(a write went around the buffer object: call .flush() after such writes)")
             self.transfer_stats["reused_bytes"] += host.nbytes

@@ -188,7 +188,7 @@ def _worker(rank, world, port, tmp, balance_nnz):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,balance_nnz", [(2, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,balance_nnz", [(2, False), (2, True), (3, True), (4, False), (8, True)])
 def test_partitioned_layer_matches_single_process(world, balance_nnz):
     from oracle import oracle as O
     O.build()

@@ -392,3 +392,44 @@ def test_config_layer_order_auto_reaches_the_modules():
     assert torch.equal(layer(1, 1, 1, x, adj).detach(), base)
     assert not torch.equal(swapped, base)                                     # another association: other roundings
     np.testing.assert_allclose(swapped.float().cpu().numpy(), base.float().cpu().numpy(), rtol=1e-2, atol=2e-3)
+
+
+def test_shim_verify_mode_catches_what_the_content_stamp_cannot(monkeypatch):
+    """A write that goes around the buffer object AND misses the bytes the content stamp samples (large buffers are
+    fingerprinted by their ends and a strided sample) leaves a stale device mirror: SGX_SHIM_VERIFY=1 compares every mirror
+    in full and says so; flush() -- pynq's own call for "the host wrote" -- repairs it."""
+    from sgracex1_amd import pynq_shim
+    n, m, p = 4096, 256, 16
+    rng = np.random.default_rng(3)
+    ip = pynq_shim.Overlay("gnn_all.bit").mmult_top_0
+    rm = ip.register_map
+    deg = rng.integers(1, 6, n)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(deg)
+    nnz = int(rp[-1])
+    bufs = {k: pynq_shim.allocate(shape, dt) for k, shape, dt in [
+        ("rp", n + 1, np.int32), ("ci", nnz, np.int32), ("va", nnz, np.float16), ("X", n * m, np.float16),
+        ("B", p * m, np.float16), ("D", n * p, np.float16)]}
+    bufs["rp"][:] = rp
+    bufs["ci"][:] = rng.integers(0, n, nnz)
+    bufs["va"][:] = rng.random(nnz).astype(np.float16)
+    bufs["X"][:] = rng.random(n * m).astype(np.float16)
+    bufs["B"][:] = (rng.random(p * m) - 0.5).astype(np.float16)
+    rm.N_adj = rm.M_adj = n
+    rm.M_fea, rm.P_w, rm.relu, rm.gemm_mode = m, p, 0, 1
+    rm.rowPtr_adj1_offset_1, rm.columnIndex_adj1_offset_1 = bufs["rp"].physical_address, bufs["ci"].physical_address
+    rm.values_adj1_offset_1, rm.values_fea1_offset_1 = bufs["va"].physical_address, bufs["X"].physical_address
+    rm.B_offset_1, rm.D1_offset_1 = bufs["B"].physical_address, bufs["D"].physical_address
+    rm.CTRL.AP_START = 1
+    first = np.asarray(bufs["D"]).copy()
+    assert bufs["X"].nbytes > (1 << 20)
+    raw = np.asarray(bufs["X"])
+    raw[(4096 + 200) // 2] += np.float16(1)                  # around the buffer object, between two sampled blocks
+    rm.CTRL.AP_START = 1
+    assert np.array_equal(np.asarray(bufs["D"]), first)       # the stale mirror was used: the documented limit of the stamp
+    monkeypatch.setenv("SGX_SHIM_VERIFY", "1")
+    with pytest.raises(RuntimeError, match="stale"):
+        rm.CTRL.AP_START = 1
+    bufs["X"].flush()
+    rm.CTRL.AP_START = 1
+    assert not np.array_equal(np.asarray(bufs["D"]), first)
