@@ -95,7 +95,11 @@ float sgx_plan_natural_utilization(const sgx_plan *plan);
 int sgx_plan_reordered(const sgx_plan *plan);
 /* One of the plan's device arrays copied to dst (device, int32, `capacity` entries) for inspection and tests:
  * which = 0 long_row, 1 long_first, 2 task_row, 3 task_e0, 4 task_e1, 5 row_order, 6 win_order (the rows of every 64-row
- * window by length, one byte per row, four to an int32; built for matrices of 2^20 entries and more without long rows).  Returns the array's length
+ * window by length, one byte per row, four to an int32; built for matrices of 2^20 entries and more without long rows),
+ * 7 scan_win (per boundary g = 0 .. ceil(nnz / 64) between windows of 64 stored entries: the first row starting at or
+ * behind entry 64 g and its first entry, then the same pair or -- when the row before is a long one -- that row and its
+ * first entry: the row-aligned entry ranges of the GAT aggregate's scan; built for plans cut at 256 entries or without a
+ * longer row).  Returns the array's length
  * (dst NULL: the length only) or a negative sgx error. */
 int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream);
 

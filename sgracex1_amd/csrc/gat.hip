@@ -14,11 +14,11 @@
 // of Wh.  sym_norm2's self loops (SG.py:42) keep the plain path away from this case, the quantised
 // adjacency does not (small values round to 0).  `fill_dead_rows` selects that result (one more
 // pass over Wh for the column means); without it such rows produce 0.
-#include "sgx_device.h"
+#include "gat_device.h"
 
 #include <stdlib.h>
 
-#include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -59,8 +59,6 @@ __global__ __launch_bounds__(kBlock) void gat_scores_kernel(int n_rows, int n_fe
     if (r < n_rows && sub == 0) { s1[r] = p1; s2[r] = p2; }
 }
 
-__device__ __forceinline__ float leaky(float x, float alpha) { return x > 0.0f ? x : x * alpha; }
-
 // ReLU (SG.py:660-661), then the quantised layer's deq_o factor on fp32 outputs (SG.py:666-667; 0 = off)
 template <typename T>
 __device__ __forceinline__ T gat_finish(float sum, int relu, float out_scale)
@@ -71,20 +69,6 @@ __device__ __forceinline__ T gat_finish(float sum, int relu, float out_scale)
         if (out_scale != 0.0f) v = v * out_scale;
     }
     return v;
-}
-
-// merge two online-softmax states (m, l); (-inf, 0) is the empty state
-__device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, float l2)
-{
-    const float mn = fmaxf(m, m2);
-    if (mn == -INFINITY) { m = mn; l = 0.0f; return; }
-    l = l * expf(m - mn) + l2 * expf(m2 - mn);
-    m = mn;
-}
-
-__device__ __forceinline__ float rescale_factor(float m_old, float m_new)
-{
-    return m_old == -INFINITY ? 0.0f : expf(m_old - m_new);        // (-inf) - (-inf) never reaches expf
 }
 
 template <typename T, int VEC, int LPR>
@@ -878,31 +862,6 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_1head_kernel(
     }
 }
 
-// the scores of heads [hb0, hb0 + 8) of node c: two 16-byte loads when the row of 8 floats is aligned (n_heads a
-// multiple of 8 and an aligned table), else element loads; entries past n_heads are 0
-__device__ __forceinline__ void load_scores8(const float *__restrict__ s2, int64_t c, int n_heads, int hb0, bool vec, float *out)
-{
-    if (vec) {
-        const float4 a = *reinterpret_cast<const float4 *>(s2 + c * n_heads + hb0);
-        const float4 b = *reinterpret_cast<const float4 *>(s2 + c * n_heads + hb0 + 4);
-        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = hb0 + k < n_heads ? s2[c * n_heads + hb0 + k] : 0.0f;
-    }
-}
-__device__ __forceinline__ void store8(float *__restrict__ dst, int64_t idx, int n_heads, int hb0, bool vec, const float *v)
-{
-    if (vec) {
-        *reinterpret_cast<float4 *>(dst + idx * n_heads + hb0) = float4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<float4 *>(dst + idx * n_heads + hb0 + 4) = float4{v[4], v[5], v[6], v[7]};
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (hb0 + k < n_heads) dst[idx * n_heads + hb0 + k] = v[k];
-    }
-}
-
 // short rows, several heads: one lane per (row, head), LH = heads rounded up to a power of two lanes per row.  The
 // lanes of a row read the same column indices and one contiguous piece of the score / weight rows (LH x 4 bytes).
 // A row of up to kAloneEdges edges is taken in ONE pass with everything in registers: its column indices, then its
@@ -1211,44 +1170,67 @@ __global__ __launch_bounds__(kBlock) void gat_scores_rows_kernel(int n_rows, int
     }
 }
 
-// long rows, step 1: one wavefront per task, its (max, sum) per head; E of its edges
+// long rows, step 1: one wavefront per task -- its (max, sum) per head, E of its entries, and the scores themselves left
+// in W (-inf for a masked entry), so that step 3 streams them back instead of gathering a second time.  256 entries a
+// pass: columns and values requested together, then their score rows (one entry per lane and pass was a chain of two
+// memory round trips per 64 entries: 100 us for the 18 M long-row entries of a 29 M-entry R-MAT graph).
 template <typename T, int HB>
 __global__ __launch_bounds__(kBlock) void gat_alpha_task_stats_kernel(
     int n_tasks, int n_heads, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
     const int32_t *__restrict__ task_e1, const int32_t *__restrict__ col, const T *__restrict__ val,
-    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, float *__restrict__ E,
+    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, float *__restrict__ E, float *__restrict__ W,
     float *__restrict__ pm, float *__restrict__ pl)
 {
+    constexpr int U = 4;
     const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (task >= n_tasks) return;
     const int lane = threadIdx.x & 63;
     const int64_t r = task_row[task];
     const int te0 = task_e0[task], te1 = task_e1[task];
-    const bool vec8 = HB == 8 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(E)) % 16 == 0;
+    if (te1 <= te0) return;
+    const bool vec = HB >= 4 && (reinterpret_cast<uintptr_t>(s1) | reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(E) |
+                                 reinterpret_cast<uintptr_t>(W)) % 16 == 0;
     for (int hb0 = 0; hb0 < n_heads; hb0 += HB) {
         float si[HB], m[HB], l[HB];
+        load_scores<HB>(s1, r, n_heads, hb0, vec, si);
 #pragma unroll
-        for (int h = 0; h < HB; ++h) { si[h] = s1[r * n_heads + hb0 + h]; m[h] = -INFINITY; l[h] = 0.0f; }
-        for (int idx = te0 + lane; idx < te1; idx += 64) {
-            const int c = col[idx];
-            const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
-            if constexpr (HB == 8) {
-                float sc[8];
-                load_scores8(s2, c, n_heads, hb0, vec8, sc);
+        for (int h = 0; h < HB; ++h) { m[h] = -INFINITY; l[h] = 0.0f; }
+        for (int i0 = te0; i0 < te1; i0 += 64 * U) {
+            int c[U];
+            unsigned live = 0u;
 #pragma unroll
-                for (int h = 0; h < 8; ++h) sc[h] = leaky(si[h] + sc[h], alpha);
-                if (E) store8(E, idx, n_heads, hb0, vec8, sc);
-                if (pos) {
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + 64 * u + lane, at = min(idx, te1 - 1);
+                c[u] = col[at];
+                live |= (idx < te1 && Elem<T>::to_f32(val[at]) > 0.0f) ? (1u << u) : 0u;
+            }
+            float x[U][HB];
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) online_add(m[h], l[h], sc[h]);
-                }
-            } else {
+            for (int u = 0; u < U; ++u) load_scores<HB>(s2, (int64_t)c[u], n_heads, hb0, vec, x[u]);
+            float mk[HB];
+#pragma unroll
+            for (int h = 0; h < HB; ++h) mk[h] = m[h];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + 64 * u + lane;
+#pragma unroll
+                for (int h = 0; h < HB; ++h) x[u][h] = leaky(si[h] + x[u][h], alpha);
+                if (E && idx < te1) store_heads<HB>(E, idx, n_heads, hb0, vec, x[u]);
 #pragma unroll
                 for (int h = 0; h < HB; ++h) {
-                    const float x = leaky(si[h] + s2[(int64_t)c * n_heads + hb0 + h], alpha);
-                    if (E) E[(int64_t)idx * n_heads + hb0 + h] = x;
-                    if (pos) online_add(m[h], l[h], x);
+                    x[u][h] = (live >> u) & 1u ? x[u][h] : -INFINITY;
+                    mk[h] = fmaxf(mk[h], x[u][h]);
                 }
+                if (idx < te1) store_heads<HB>(W, idx, n_heads, hb0, vec, x[u]);
+            }
+#pragma unroll
+            for (int h = 0; h < HB; ++h) {
+                if (mk[h] == -INFINITY) continue;
+                float sum = l[h] * rescale_factor(m[h], mk[h]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum += expf(x[u][h] - mk[h]);           // (a masked entry: exp(-inf) = 0)
+                l[h] = sum;
+                m[h] = mk[h];
             }
         }
 #pragma unroll
@@ -1263,65 +1245,59 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_task_stats_kernel(
     }
 }
 
-// long rows, step 2: the tasks of a row merged in task order (eight states requested at a time), and the row's state
-// written back over every one of its tasks' states, so that step 3 can run per TASK and read pm / pl at its own index
+// long rows, step 2: one wavefront per (long row, head) -- its tasks' states merged, 64 at a time in a fixed lane order,
+// and the row's state written back over every one of them, so that step 3 can run per TASK and read pm / pl at its own
+// index (a thread per row and head walking up to hundreds of tasks one after the other took 38 us)
 __global__ __launch_bounds__(kBlock) void gat_alpha_long_merge_kernel(
     int n_long, int n_heads, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
     float *__restrict__ pm, float *__restrict__ pl, float *__restrict__ row_m, float *__restrict__ row_l,
     unsigned char *__restrict__ dead)
 {
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= (int64_t)n_long * n_heads) return;
-    const int i = (int)(gid / n_heads), h = (int)(gid % n_heads);
-    float m = -INFINITY, l = 0.0f;
+    const int64_t pair = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (pair >= (int64_t)n_long * n_heads) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(pair / n_heads), h = (int)(pair % n_heads);
     const int t0 = long_first[i], t_end = long_first[i + 1];
-    int t = t0;
-    for (; t + 8 <= t_end; t += 8) {
-        float vm[8], vl[8];
+    float m = -INFINITY, l = 0.0f;
+    for (int t = t0 + lane; t < t_end; t += 64) softmax_merge(m, l, pm[(int64_t)t * n_heads + h], pl[(int64_t)t * n_heads + h]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { vm[u] = pm[(int64_t)(t + u) * n_heads + h]; vl[u] = pl[(int64_t)(t + u) * n_heads + h]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) softmax_merge(m, l, vm[u], vl[u]);
+    for (int off = 1; off < 64; off <<= 1) softmax_merge(m, l, __shfl_xor(m, off), __shfl_xor(l, off));
+    m = __shfl(m, 0);                           // (one lane's result for all: the merge is not symmetric in its last bits)
+    l = __shfl(l, 0);
+    for (int t = t0 + lane; t < t_end; t += 64) { pm[(int64_t)t * n_heads + h] = m; pl[(int64_t)t * n_heads + h] = l; }
+    if (lane == 0) {
+        row_m[pair] = m;
+        row_l[pair] = l;
+        if (h == 0) dead[long_row[i]] = l > 0.0f ? 0 : 1;
     }
-    for (; t < t_end; ++t) softmax_merge(m, l, pm[(int64_t)t * n_heads + h], pl[(int64_t)t * n_heads + h]);
-    row_m[gid] = m;
-    row_l[gid] = l;
-    for (t = t0; t < t_end; ++t) { pm[(int64_t)t * n_heads + h] = m; pl[(int64_t)t * n_heads + h] = l; }
-    if (h == 0) dead[long_row[i]] = l > 0.0f ? 0 : 1;
 }
 
-// long rows, step 3: the weights of their edges, one wavefront per TASK (round 2 gave every long row 16 workgroups
-// whatever its length -- 347 K workgroups for the 21.7 K long rows of a 29 M-edge R-MAT graph, most of them idle: 148 us;
-// the row's merged state lies at the task's own index after step 2)
-template <typename T>
+// long rows, step 3: the weights of their entries from the scores step 1 left in W, one wavefront per TASK (the row's
+// merged state lies at the task's own index after step 2): a streaming pass, no gathers
 __global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
-    int n_tasks, int n_heads, const int32_t *__restrict__ task_row, const int32_t *__restrict__ task_e0,
-    const int32_t *__restrict__ task_e1, const int32_t *__restrict__ col, const T *__restrict__ val,
-    const float *__restrict__ s1, const float *__restrict__ s2, float alpha, const float *__restrict__ pm,
-    const float *__restrict__ pl, float *__restrict__ W)
+    int n_tasks, int n_heads, const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1,
+    const float *__restrict__ pm, const float *__restrict__ pl, float *__restrict__ W)
 {
+    constexpr int U = 4;
     const int task = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (task >= n_tasks) return;
     const int lane = threadIdx.x & 63;
-    const int64_t row = task_row[task];
-    const int te0 = task_e0[task], te1 = task_e1[task];
-    const bool vec8 = n_heads % 8 == 0 && (reinterpret_cast<uintptr_t>(s2) | reinterpret_cast<uintptr_t>(W)) % 16 == 0;
-    for (int idx = te0 + lane; idx < te1; idx += 64) {
-        const bool pos = Elem<T>::to_f32(val[idx]) > 0.0f;
-        const int c = col[idx];
-        for (int hb0 = 0; hb0 < n_heads; hb0 += 8) {
-            float sc[8];
-            load_scores8(s2, c, n_heads, hb0, vec8, sc);
+    const int64_t f0 = (int64_t)task_e0[task] * n_heads, f1 = (int64_t)task_e1[task] * n_heads;
+    if (f1 <= f0) return;
+    const float *tm = pm + (int64_t)task * n_heads, *tl = pl + (int64_t)task * n_heads;
+    float *Wt = W + f0;
+    const int n = (int)(f1 - f0);                                  // (a task's scores: entries x heads, well under 2^31)
+    const bool pow2 = (n_heads & (n_heads - 1)) == 0;
+    for (int j0 = 0; j0 < n; j0 += 64 * U) {
+        float x[U];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float w = 0.0f;
-                if (hb0 + k < n_heads) {
-                    const float m = pm[(int64_t)task * n_heads + hb0 + k], l = pl[(int64_t)task * n_heads + hb0 + k];
-                    if (pos && l > 0.0f) w = expf(leaky(s1[row * n_heads + hb0 + k] + sc[k], alpha) - m) / l;
-                }
-                sc[k] = w;
-            }
-            store8(W, idx, n_heads, hb0, vec8, sc);
+        for (int u = 0; u < U; ++u) x[u] = Wt[min(j0 + 64 * u + lane, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u + lane;
+            const int h = pow2 ? (j & (n_heads - 1)) : j % n_heads;        // (the task begins at head 0 of an entry)
+            const float m = tm[h], l = tl[h];
+            if (j < n) Wt[j] = l > 0.0f ? expf(x[u] - m) * (1.0f / l) : 0.0f;     // (the expression of gat_weighted_kernel's from_scores)
         }
     }
 }
@@ -1339,7 +1315,8 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
     const float *__restrict__ W, unsigned w_bytes, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes,
     T *__restrict__ D, int64_t ldd, int relu, float out_scale, int long_threshold, int vec_store,
     const int32_t *__restrict__ row_order, int split_blocks, int n_tasks, const int32_t *__restrict__ task_e0,
-    const int32_t *__restrict__ task_e1, float *__restrict__ partial, int ldp, int n_multi, int short_first)
+    const int32_t *__restrict__ task_e1, float *__restrict__ partial, int ldp, int n_multi, int short_first,
+    const float *__restrict__ task_m, const float *__restrict__ task_l)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int TILE = LPR * VEC;
@@ -1350,9 +1327,18 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W), 0, w_bytes, 0x00020000);
 
     // the sums of edges [e0, e1) taken `stride` apart in pieces of LPR, for the lane's VEC columns at col0
-    auto accumulate = [&](float *acc, int e0, int e1, int stride, int col0) {
+    // from_scores (a task of a long row whose W still holds stage A's scores, -inf for a masked entry): the weight is
+    // exp(score - m) * (1 / l) with the row's merged state, formed here instead of by a pass of its own over W
+    auto accumulate = [&](auto from_scores, float *acc, int e0, int e1, int stride, int col0, const float *state_m, const float *state_l) {
+        constexpr bool XF = decltype(from_scores)::value;
         const unsigned col_off = col0 < n_feat ? (unsigned)col0 * (unsigned)sizeof(T) : kOOB;
         const unsigned my_head = HEADS ? (unsigned)((col0 < n_feat ? col0 : 0) / f_head) : 0u;
+        float xm = 0.0f, xinv = 0.0f;
+        if constexpr (XF) {
+            const float l = state_l[my_head];
+            xm = state_m[my_head];
+            xinv = l > 0.0f ? 1.0f / l : 0.0f;
+        }
         unsigned c_next = 0;
         float a_next = 0.0f;
         auto fetch = [&](int idx, unsigned &c, float &a) {
@@ -1360,7 +1346,10 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
             a = 0.0f;
             if (idx < e1) {
                 c = (unsigned)__builtin_nontemporal_load(col + idx);
-                if (!HEADS) a = __builtin_nontemporal_load(W + idx);
+                if (!HEADS) {
+                    a = __builtin_nontemporal_load(W + idx);
+                    if constexpr (XF) a = xinv > 0.0f ? expf(a - xm) * xinv : 0.0f;
+                }
             }
         };
         fetch(e0 + sub, c_next, a_next);
@@ -1377,11 +1366,13 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
                     const int t = t0 + u;
                     const unsigned cc = (unsigned)__shfl((int)c, t, LPR);
                     float aa;
-                    if (HEADS)
+                    if (HEADS) {
                         aa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                  wsrc, t < n ? ((unsigned)(base + t) * (unsigned)n_heads + my_head) * 4u : kOOB, 0, 0));
-                    else
+                        if constexpr (XF) aa = (t < n && xinv > 0.0f) ? expf(aa - xm) * xinv : 0.0f;
+                    } else {
                         aa = __shfl(a, t, LPR);
+                    }
                     Gather<T, VEC>::run(acc, aa, rsrc, (t < n && col_off != kOOB) ? cc * ld_bytes + col_off : kOOB);
                 }
             }
@@ -1397,7 +1388,8 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
             float acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-            accumulate(acc, e0 + grp * LPR, e1, 64, col0);
+            if (task_m) accumulate(std::true_type{}, acc, e0 + grp * LPR, e1, 64, col0, task_m + (int64_t)task * n_heads, task_l + (int64_t)task * n_heads);
+            else accumulate(std::false_type{}, acc, e0 + grp * LPR, e1, 64, col0, nullptr, nullptr);
 #pragma unroll
             for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
@@ -1493,7 +1485,7 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
             float acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
-            accumulate(acc, e0, e1, LPR, col0);
+            accumulate(std::false_type{}, acc, e0, e1, LPR, col0, nullptr, nullptr);
             if (live && col0 < n_feat) {
                 T out[VEC];
 #pragma unroll
@@ -1550,6 +1542,20 @@ __global__ __launch_bounds__(kBlock) void gat_dead_fill_kernel(
         for (int64_t i = (int64_t)rowptr[r] * n_heads + lane; i < (int64_t)rowptr[r + 1] * n_heads; i += 64) S[i] = uniform;
 }
 
+// Stage A's short rows in entry order (gat_scan.hip) instead of 8 rows per wavefront?
+// Measured (tools/gat_probe.py, round 3): on a power-law graph one head's short rows take 146 us in entry order against
+// 240 us as 8-row wavefronts (29 M-entry R-MAT, 11 M entries in rows up to 256); with 8 heads the log-step scans cost
+// six times the vector instructions of the per-row lanes' running maximum and sum and lose on every shape (ogbn-arxiv
+// shape 113 against 69 us), and on a uniform graph the 8-row wavefronts have no idle lanes to win back.  So: one or two
+// heads, on a plan whose short rows are scheduled in degree order -- the plan's own sign of rows of very unequal length.
+bool gat_scan_wanted(const sgx_plan *p, int n_heads)
+{
+    const int mode = sgx_tune().gat_scan;          // tuning override: 0 = never, 1 = by shape, 2 = wherever the plan allows
+    if (mode == 0 || !sgx_gat_scan_applicable(p)) return false;
+    (void)n_heads;
+    return mode == 2 || p->row_order != nullptr;
+}
+
 template <typename T, int HB>
 int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W, unsigned char *dead, float *pm, float *pl,
                     float *row_m, float *row_l)
@@ -1557,7 +1563,11 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
     const sgx_plan *p = a.plan_any;
     const int thr = p->n_long > 0 ? p->long_threshold : 0;
     const int rows_per_block = (64 / kAlphaLanes) * (kBlock / 64);
-    if (a.n_heads == 1) {
+    if (gat_scan_wanted(p, a.n_heads)) {     // the rows up to the cut in entry order (gat_scan.hip); the longer ones below, as ever
+        const int rc = sgx_gat_alpha_scan(sizeof(T) == 2 ? SGX_F16 : SGX_F32, a.n_rows, a.n_heads, p, a.rowptr, a.col, a.val, s1, s2,
+                                          a.alpha, W, a.E, a.fill ? dead : nullptr, a.stream);
+        if (rc != SGX_OK) return rc;
+    } else if (a.n_heads == 1) {
         const dim3 grid1((unsigned)((a.n_rows + rows_per_block - 1) / rows_per_block));
         hipLaunchKernelGGL((gat_alpha_rows_1head_kernel<T>), grid1, dim3(kBlock), 0, a.stream, a.n_rows, a.rowptr, a.col,
                            (const T *)a.val, (unsigned)(p->nnz * 4), s1, s2, (unsigned)((size_t)a.n_cols * 4), a.alpha, thr, W, a.E, dead);
@@ -1588,16 +1598,17 @@ int gat_alpha_stage(const GatArgs &a, const float *s1, const float *s2, float *W
     if (thr > 0) {
         hipLaunchKernelGGL((gat_alpha_task_stats_kernel<T, HB>), dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock),
                            0, a.stream, p->n_tasks, a.n_heads, p->task_row, p->task_e0, p->task_e1, a.col, (const T *)a.val, s1,
-                           s2, a.alpha, a.E, pm, pl);
+                           s2, a.alpha, a.E, W, pm, pl);
         SGX_LAUNCH_CHECK();
         const int64_t pairs = (int64_t)p->n_long * a.n_heads;
-        hipLaunchKernelGGL(gat_alpha_long_merge_kernel, dim3((unsigned)((pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream,
-                           p->n_long, a.n_heads, p->long_row, p->long_first, pm, pl, row_m, row_l, dead);
+        hipLaunchKernelGGL(gat_alpha_long_merge_kernel, dim3((unsigned)((pairs + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                           a.stream, p->n_long, a.n_heads, p->long_row, p->long_first, pm, pl, row_m, row_l, dead);
         SGX_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_alpha_long_write_kernel<T>), dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0,
-                           a.stream, p->n_tasks, a.n_heads, p->task_row, p->task_e0, p->task_e1, a.col, (const T *)a.val, s1, s2,
-                           a.alpha, pm, pl, W);
-        SGX_LAUNCH_CHECK();
+        if (a.S) {                             // the caller wants the weights themselves; otherwise stage B forms them from the scores
+            hipLaunchKernelGGL(gat_alpha_long_write_kernel, dim3((p->n_tasks + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0,
+                               a.stream, p->n_tasks, a.n_heads, p->task_e0, p->task_e1, pm, pl, W);
+            SGX_LAUNCH_CHECK();
+        }
     }
     return SGX_OK;
 }
@@ -1661,7 +1672,8 @@ int gat_two_stage(const GatArgs &a)
     hipLaunchKernelGGL((gat_weighted_kernel<T, VEC, LPR, HEADS_, SHORT_>), grid_b, dim3(kBlock), 0, a.stream, n_work, a.n_feat,     \
                        a.n_heads, f_head, a.rowptr, a.col, W, w_bytes, (const T *)a.Wh, a.h_bytes, a.ld_bytes, (T *)a.D, a.ldd,      \
                        a.relu, a.out_scale, thr, a.vec_store, order, split_blocks, n_tasks, n_tasks ? p->task_e0 : nullptr,         \
-                       n_tasks ? p->task_e1 : nullptr, pacc, ldp, n_multi, short_first)
+                       n_tasks ? p->task_e1 : nullptr, pacc, ldp, n_multi, short_first,                                            \
+                       (n_tasks && !a.S) ? pm : nullptr, (n_tasks && !a.S) ? pl : nullptr)
     if (a.n_heads > 1) {
         if (short_tail) SGX_GAT_WEIGHTED(1, true);
         else SGX_GAT_WEIGHTED(1, false);

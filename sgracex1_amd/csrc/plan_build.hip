@@ -326,6 +326,28 @@ __global__ __launch_bounds__(kThreads) void plan_window_order_kernel(const int32
     win_order[w * 64 + lane] = (uint8_t)(key & 63u);
 }
 
+// scan_win (sgx_internal.h): a thread per window of kScanGranule entries, lower bound of the window's first entry among
+// the row starts
+__global__ __launch_bounds__(kThreads) void plan_scan_windows_kernel(const int32_t *__restrict__ rowptr, int n_rows, int64_t nnz,
+                                                                     int64_t n_win, int long_threshold, int32_t *__restrict__ scan_win)
+{
+    const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (g > n_win) return;
+    const int64_t e64 = g * kScanGranule;
+    const int e = (int)(e64 < nnz ? e64 : nnz);
+    int lo = 0, hi = n_rows;                       // the first r in [0, n_rows] with rowptr[r] >= e (rowptr[n_rows] = nnz >= e)
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (rowptr[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    const int first = rowptr[lo];
+    const bool long_before = lo > 0 && first - rowptr[lo - 1] > long_threshold;
+    scan_win[4 * g] = lo;
+    scan_win[4 * g + 1] = first;
+    scan_win[4 * g + 2] = long_before ? lo - 1 : lo;
+    scan_win[4 * g + 3] = long_before ? rowptr[lo - 1] : first;
+}
+
 // The builder's own scratch comes from the stream-ordered pool and goes back to it on the same stream (on every way
 // out): no synchronisation is needed to free it after the kernels that read it, and a builder called per mini-batch
 // does not pay hipMalloc / hipFree each time.
@@ -359,6 +381,8 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
     p->long_row = p->long_first = p->task_row = p->task_e0 = p->task_e1 = nullptr;
     p->row_order = nullptr;
     p->win_order = nullptr;
+    p->scan_win = nullptr;
+    p->n_scan_win = 0;
     p->n_ordered = 0;
     p->n_multi = -1;
     p->max_degree = 0;
@@ -458,6 +482,16 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
                            rowPtr, n_rows, n_windows, p->win_order);
         SGX_LAUNCH_CHECK();
     }
+    // the row-aligned entry windows of the GAT aggregate's scan (gat_scan.hip): plans whose longer rows are cut at its row
+    // limit (Csr.gat_plan), or that hold no longer row
+    if (p->nnz > 0 && p->nnz < ((int64_t)1 << 30) && (p->n_long > 0 ? long_threshold == kScanMaxRow : p->max_degree <= kScanMaxRow)) {
+        p->n_scan_win = (p->nnz + kScanGranule - 1) / kScanGranule;
+        SGX_HIP_CHECK(hipMalloc(&p->scan_win, sizeof(int32_t) * 4 * (size_t)(p->n_scan_win + 1)));
+        launched_after_readback = true;
+        hipLaunchKernelGGL(plan_scan_windows_kernel, dim3((unsigned)((p->n_scan_win + 1 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           rowPtr, n_rows, p->nnz, p->n_scan_win, p->n_long > 0 ? long_threshold : 0x7FFFFFFF, p->scan_win);
+        SGX_LAUNCH_CHECK();
+    }
     // A plan is used from any stream (the partitioned layer launches on side streams): its arrays must be complete when
     // this returns, not merely ordered on `stream`.  Only a plan with long rows or a degree order has kernels behind the
     // read-back; the common plan (uniform graph, mini-batch) returned complete at the read-back's synchronisation.
@@ -479,11 +513,12 @@ extern "C" void sgx_plan_destroy(sgx_plan *plan)
     if (plan->long_row) (void)hipFree(plan->long_row);     // one blob, long_row is its base
     if (plan->row_order) (void)hipFree(plan->row_order);
     if (plan->win_order) (void)hipFree(plan->win_order);
+    if (plan->scan_win) (void)hipFree(plan->scan_win);
     delete plan;
 }
 
 // One of the plan's arrays copied (device to device) for inspection: 0 long_row, 1 long_first, 2 task_row, 3 task_e0,
-// 4 task_e1, 5 row_order, 6 win_order (its bytes, four to an int32).  Returns the array's length (dst == NULL: the length only) or a negative sgx error.
+// 4 task_e1, 5 row_order, 6 win_order (its bytes, four to an int32), 7 scan_win (four per window boundary).  Returns the array's length (dst == NULL: the length only) or a negative sgx error.
 extern "C" int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream)
 {
     if (!plan) return SGX_ERR_NULL;
@@ -500,6 +535,7 @@ extern "C" int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst
         src = reinterpret_cast<const int32_t *>(plan->win_order);
         n = plan->win_order ? ((int64_t)plan->n_rows + 63) / 64 * 16 : 0;
         break;
+    case 7: src = plan->scan_win; n = plan->scan_win ? 4 * (plan->n_scan_win + 1) : 0; break;
     default: return SGX_ERR_UNSUPPORTED;
     }
     if (!dst || n == 0) return n;

@@ -24,7 +24,8 @@ typedef _Float16 f16;
 // (Cora, MUTAG).  Sizing a scratch and launching on it therefore see the same settings.  A process that changes a
 // variable afterwards (tests and probes that compare two forms in one process) calls sgx_reload_env().
 struct sgx_tuning {
-    bool gat_one_pass, gat_no_fused_scores, gat_no_scan;
+    bool gat_one_pass, gat_no_fused_scores;
+    int gat_scan;              // SGX_GAT_SCAN: 0 = the GAT aggregate's short rows never in entry order, 1 = by shape (default), 2 = always
     bool xw_no_wlds, xw_no_stationary_f32, xw_sparse_no_lds, xw_short_tiles, xw_no_lds;
     bool xtg_scalar, xtg_wave_tiles;
     bool spmm_no_short_tail;      // the one-step tail of a degree order through the sblock path (as in round 2)
@@ -67,6 +68,14 @@ struct sgx_plan {
     // (xw_sparse_lds.hip; round 2 sorted every window inside the kernel, 7 % of its instructions); built for the
     // matrices that form can take (2^20 entries and more, no long rows), NULL otherwise.
     uint8_t *win_order;    // [ceil(n_rows / 64) * 64]
+    // Where the windows of kScanGranule stored entries meet among the rows, per boundary g = 0 .. n_scan_win (entry
+    // g * kScanGranule): scan_win[4 g] = the first row that starts at or behind it, [4 g + 1] = that row's first entry --
+    // where the window behind the boundary begins; [4 g + 2], [4 g + 3] = the same pair, or the row before and ITS first
+    // entry when that row is a long one (it belongs to the tasks) -- where the window before the boundary ends.  The
+    // entry-order form of the GAT aggregate's softmax weights (gat_scan.hip) takes its row-aligned ranges from it; built
+    // for plans that cut at 256 entries (Csr.gat_plan) or hold no longer row, NULL otherwise.
+    int32_t *scan_win;     // [4 (n_scan_win + 1)]
+    int64_t n_scan_win;
     float natural_utilization;   // share of lane-group steps doing work when rows are packed in natural order
     int max_degree;              // the longest row (lets a caller skip launches that only serve rows above some length)
 };
@@ -146,6 +155,14 @@ int sgx_gat_aggregate_ep(int dtype, int relu, int fill_dead_rows, int n_rows, in
                          const void *attention, void *D, int64_t ldd, float *E, float *S, const sgx_plan *plan,
                          float *s_scratch, hipStream_t stream, float out_scale, const float *ext_fill = nullptr, int ext_n = 0,
                          int scores_ready = 0);
+// gat_scan.hip: the softmax weights of the stored entries of every row of up to kScanMaxRow entries (stage A of the
+// two-stage aggregate) as a segmented scan in entry order; longer rows are the plan's tasks
+constexpr int kScanGranule = 64, kScanMaxRow = 256;
+bool sgx_gat_scan_applicable(const sgx_plan *plan);
+int sgx_gat_alpha_scan(int dtype, int n_rows, int n_heads, const sgx_plan *plan, const int32_t *rowptr, const int32_t *col,
+                       const void *val, const float *s1, const float *s2, float alpha, float *W, float *E, unsigned char *dead,
+                       hipStream_t stream);
+
 // GAT layer: the attention scores formed by the X.W kernel's epilogue (fp16, heads of 32 columns, two-stage aggregate)
 bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan);
 float *sgx_gat_score_partials(float *s_scratch, int n_cols, int n_feat, int n_heads, int fill_dead_rows);

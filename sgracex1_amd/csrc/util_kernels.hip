@@ -283,7 +283,7 @@ void load_tuning()
     auto num = [](const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; };
     t.gat_one_pass = flag("SGX_GAT_ONE_PASS");
     t.gat_no_fused_scores = flag("SGX_GAT_NO_FUSED_SCORES");
-    t.gat_no_scan = flag("SGX_GAT_NO_SCAN");
+    { const char *v = getenv("SGX_GAT_SCAN"); t.gat_scan = v ? atoi(v) : 1; }
     t.xw_no_wlds = flag("SGX_XW_NO_WLDS");
     t.xw_no_stationary_f32 = flag("SGX_XW_NO_STATIONARY_F32");
     t.xw_sparse_no_lds = flag("SGX_XW_SPARSE_NO_LDS");

@@ -116,7 +116,7 @@ class Plan:
     def reordered(self):
         return bool(lib.sgx_plan_reordered(self._h))
 
-    ARRAYS = ("long_row", "long_first", "task_row", "task_e0", "task_e1", "row_order", "win_order")
+    ARRAYS = ("long_row", "long_first", "task_row", "task_e0", "task_e1", "row_order", "win_order", "scan_win")
 
     def export(self, name):
         """One of the schedule's device arrays (ARRAYS) as an int32 tensor -- for inspection and tests."""
@@ -193,7 +193,8 @@ class Csr:
     @property
     def gat_plan(self):
         """The schedule for the edge-softmax aggregate: hub rows cut at 256 edges.  Its first stage (the softmax weights,
-        csrc/gat.hip) keeps a row of up to 256 edges in registers; longer rows go through the plan's tasks.  Measured on
+        csrc/gat.hip, gat_scan.hip) keeps a row of up to 256 edges in registers -- per row, or per window of stored entries
+        on a plan in degree order (the plan's scan_win, built for this cut) -- longer rows go through the plan's tasks.  Measured on
         R-MAT graphs of 2.4 M / 7.5 M / 29 M edges (tools/plan_cut_probe.py): 256 is the best or within 2 % of it for one
         head and for 8, while the plain aggregation prefers 512 / 1024 / 2048 (Plan's default).  The plan also tells the
         library the stored-entry count it sizes the weights with."""

@@ -166,3 +166,38 @@ def test_plan_window_order_of_the_sparse_feature_stage():
     hub[5] = 200_000
     cut = ops.Plan(torch.as_tensor(_rowptr(hub).astype(np.int32), device=dev))
     assert cut.long_rows == 1 and cut.export("win_order").numel() == 0
+
+
+@pytest.mark.parametrize("kind", ["uniform", "powerlaw", "empty", "hubs"])
+def test_plan_entry_windows_of_the_gat_scan(kind):
+    """scan_win: per boundary between windows of 64 stored entries, the first row starting at or behind it with its first
+    entry, and where the window before it ends for the scan -- the same pair, or the row before and its first entry when
+    that row is a long one (it belongs to the tasks).  Built for plans cut at 256 entries (Csr.gat_plan) or without a
+    longer row; not for other cuts."""
+    from sgracex1_amd import ops
+    rng = np.random.default_rng(len(kind))
+    deg = _degrees(kind, 70_003, rng).astype(np.int64)
+    if kind == "hubs":
+        deg[[5, 6, 40_000]] = [257, 256, 1_000]
+    rp_t = _rowptr(deg)
+    rp = rp_t.cpu().numpy().astype(np.int64)
+    nnz = int(rp[-1])
+    plan = ops.Plan(rp_t, 256, 256)
+    win = plan.export("scan_win").cpu().numpy().astype(np.int64)
+    if nnz == 0:
+        assert win.size == 0
+        return
+    n_win = (nnz + 63) // 64
+    assert win.size == 4 * (n_win + 1)
+    win = win.reshape(n_win + 1, 4)
+    e = np.minimum(np.arange(n_win + 1) * 64, nnz)
+    first = np.searchsorted(rp, e, side="left")                       # first row with rowptr >= e
+    assert (win[:, 0] == first).all() and (win[:, 1] == rp[first]).all()
+    before = np.maximum(first - 1, 0)
+    long_before = (first > 0) & (rp[first] - rp[before] > 256) & (plan.long_rows > 0)
+    assert (win[:, 2] == np.where(long_before, before, first)).all()
+    assert (win[:, 3] == np.where(long_before, rp[before], rp[first])).all()
+    # every row of up to 256 entries lies in exactly one window's range, whole
+    starts, ends = win[:-1, 1], win[1:, 3]
+    assert (ends - starts <= 64 + 255).all()
+    assert ops.Plan(rp_t, 512, 512).export("scan_win").numel() == (0 if (deg > 512).any() else win.size)

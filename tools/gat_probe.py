@@ -3,6 +3,8 @@
 tuned on, a few launches each -- for `rocprofv3 --kernel-trace --stats` (per-kernel times) or timed alone:
 
     python3 tools/gat_probe.py [arxiv|arxiv-rmat|rmat20] [--heads 1|8] [--launches 20]
+
+SGX_GAT_SCAN=0 / 2 in the environment: stage A's short rows never / always in entry order (gat_scan.hip; default: by shape).
 """
 import argparse
 import json
