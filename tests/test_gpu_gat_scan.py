@@ -78,22 +78,36 @@ def _check(A, heads, f_head, dtype, seed, fill=None):
     return D, S2, row
 
 
+def _filled(head, rng, n=58_000):
+    """the case's rows, then ordinary rows up to 2^20 entries and more: smaller matrices are cut at 64 entries whatever the
+    caller's plan says (plan_build.hip), and the entry windows exist for the cut at 256 only"""
+    return np.concatenate([head, rng.integers(0, 40, n)])
+
+
 DEGREES = {
-    "mixed": lambda rng: rng.integers(0, 41, 20_000),
-    "hubs": lambda rng: np.concatenate([np.full(1000, 5), [100_000], np.full(500, 3), [513, 512, 511, 256, 255, 257, 64, 63, 65, 1, 0, 0, 2],
-                                        [3000, 0, 7, 40_000], rng.integers(0, 20, 3000)]),
-    "empty_runs": lambda rng: np.concatenate([np.zeros(200), rng.integers(1, 9, 500), np.zeros(300), [700], np.zeros(64), [1],
-                                              np.zeros(129), rng.integers(0, 3, 4000), np.zeros(1000)]),
-    "one_entry_rows": lambda rng: np.ones(30_000),
+    "mixed": lambda rng: rng.integers(0, 41, 60_000),
+    "hubs": lambda rng: _filled(np.concatenate([np.full(1000, 5), [100_000], np.full(500, 3),
+                                                [513, 512, 511, 256, 255, 257, 64, 63, 65, 1, 0, 0, 2], [3000, 0, 7, 40_000],
+                                                rng.integers(0, 20, 3000)]), rng),
+    "empty_runs": lambda rng: _filled(np.concatenate([np.zeros(200), rng.integers(1, 9, 500), np.zeros(300), [700], np.zeros(64), [1],
+                                                      np.zeros(129), rng.integers(0, 3, 4000), np.zeros(1000)]), rng),
+    "one_entry_rows": lambda rng: np.ones(1_100_000),
+    "on_the_windows": lambda rng: _filled(np.concatenate([np.full(10, 512), np.full(10, 256), np.full(3, 1024), [64, 64, 128, 192, 64],
+                                                          np.full(40, 128), np.full(7, 256), [255, 1, 256, 256, 257, 255]]), rng),
+    "two_entry_rows_then_hub": lambda rng: _filled(np.concatenate([np.full(5000, 2), [20_000], np.full(5000, 2)]), rng),
+    "long_rows_back_to_back": lambda rng: _filled(np.concatenate([[300, 300, 257, 256, 1, 5000, 4000, 0, 0, 256, 300], np.zeros(70),
+                                                                  [300, 2, 300]]), rng),
+    "rows_of_256": lambda rng: _filled(np.array([0, 256, 0, 0, 256, 255, 1, 0]), rng),
+    # small matrices (cut at 64: the row-shaped kernels whatever SGX_GAT_SCAN says; without a longer row the windows exist)
     "one_row": lambda rng: np.array([5000]),
     "one_row_between_empty": lambda rng: np.array([0, 5000, 0]),
-    "on_the_ranges": lambda rng: np.concatenate([np.full(10, 512), np.full(10, 256), np.full(3, 1024), [64, 64, 128, 192, 64]]),
     "one_entry": lambda rng: np.array([0, 1, 0]),
     "63": lambda rng: np.array([63]),
     "64": lambda rng: np.array([30, 34]),
     "65": lambda rng: np.array([64, 1]),
-    "two_entry_rows_then_hub": lambda rng: np.concatenate([np.full(5000, 2), [20_000], np.full(5000, 2)]),
 }
+SCANNED = ("mixed", "hubs", "empty_runs", "one_entry_rows", "on_the_windows", "two_entry_rows_then_hub", "long_rows_back_to_back",
+           "rows_of_256", "one_entry", "63", "64", "65")
 
 
 @pytest.mark.parametrize("name", list(DEGREES))
@@ -105,6 +119,7 @@ def test_scan_weights(name, dtype, heads, f_head):
     deg = DEGREES[name](rng).astype(np.int64)
     n_cols = max(len(deg), 50)
     A = _csr(deg, n_cols, dtype, seed=heads * 31 + f_head)
+    assert (A.gat_plan.export("scan_win").numel() > 0) == (name in SCANNED)        # (the scan is what SGX_GAT_SCAN=2 runs)
     _check(A, heads, f_head, dtype, seed=heads + f_head, fill=False)
 
 
@@ -112,11 +127,12 @@ def test_scan_weights(name, dtype, heads, f_head):
 def test_scan_rows_without_a_live_entry(dtype, heads, f_head):
     """Rows whose stored entries are all masked, and rows without entries: weight 0 on every entry, and with the
     dense-emulation rule (SG.py:638-641) the mean row of Wh and S = 1/N -- a short row, a row of exactly one range, a hub
-    over many ranges, a row crossing a range end, the last row."""
+    over many windows, rows of the scan's own length limit, the last row."""
     rng = np.random.default_rng(5)
-    deg = np.concatenate([rng.integers(1, 30, 3000), [512, 9000, 700], rng.integers(0, 30, 3000), [40]]).astype(np.int64)
-    dead = [0, 17, 3000, 3001, 3002, len(deg) - 1]
+    deg = np.concatenate([rng.integers(1, 30, 3000), [512, 9000, 700, 256, 200], rng.integers(0, 40, 60_000), [40]]).astype(np.int64)
+    dead = [0, 17, 3000, 3001, 3002, 3003, 3004, len(deg) - 1]
     A = _csr(deg, len(deg), dtype, seed=9, dead_rows=dead)
+    assert A.gat_plan.export("scan_win").numel() > 0
     D, S, row = _check(A, heads, f_head, dtype, seed=3, fill=False)
     dead_t = torch.tensor(dead, device="cuda")
     assert not D[dead_t].any()

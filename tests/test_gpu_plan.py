@@ -176,17 +176,18 @@ def test_plan_entry_windows_of_the_gat_scan(kind):
     longer row; not for other cuts."""
     from sgracex1_amd import ops
     rng = np.random.default_rng(len(kind))
-    deg = _degrees(kind, 70_003, rng).astype(np.int64)
+    deg = _degrees(kind, 400_003, rng).astype(np.int64)                 # (a small matrix is cut at its own threshold, whatever the caller says)
     if kind == "hubs":
         deg[[5, 6, 40_000]] = [257, 256, 1_000]
-    rp_t = _rowptr(deg)
-    rp = rp_t.cpu().numpy().astype(np.int64)
+    rp = _rowptr(deg)
+    rp_t = torch.as_tensor(rp, dtype=torch.int32, device=dev)
     nnz = int(rp[-1])
     plan = ops.Plan(rp_t, 256, 256)
     win = plan.export("scan_win").cpu().numpy().astype(np.int64)
     if nnz == 0:
         assert win.size == 0
         return
+    assert plan.long_threshold == 256
     n_win = (nnz + 63) // 64
     assert win.size == 4 * (n_win + 1)
     win = win.reshape(n_win + 1, 4)
