@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_VERSION 106
+#define SGX_VERSION 107
 
 typedef enum sgx_status {
     SGX_OK = 0,
@@ -98,7 +98,7 @@ int sgx_plan_reordered(const sgx_plan *plan);
  * window by length, one byte per row, four to an int32; built for matrices of 2^20 entries and more without long rows),
  * 7 scan_win (per boundary g = 0 .. ceil(nnz / 64) between windows of 64 stored entries: the first row starting at or
  * behind entry 64 g and its first entry, then the same pair or -- when the row before is a long one -- that row and its
- * first entry: the row-aligned entry ranges of the GAT aggregate's scan; built for plans cut at 256 entries or without a
+ * first entry: the row-aligned entry ranges of the GAT aggregate's scan; built for plans created with a cut of 256 entries that are cut there or hold no
  * longer row).  Returns the array's length
  * (dst NULL: the length only) or a negative sgx error. */
 int64_t sgx_plan_export(const sgx_plan *plan, int which, int32_t *dst, int64_t capacity, void *stream);

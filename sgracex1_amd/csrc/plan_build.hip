@@ -482,9 +482,10 @@ extern "C" int sgx_plan_create_ex(sgx_plan **out, const int32_t *rowPtr, int n_r
                            rowPtr, n_rows, n_windows, p->win_order);
         SGX_LAUNCH_CHECK();
     }
-    // the row-aligned entry windows of the GAT aggregate's scan (gat_scan.hip): plans whose longer rows are cut at its row
-    // limit (Csr.gat_plan), or that hold no longer row
-    if (p->nnz > 0 && p->nnz < ((int64_t)1 << 30) && (p->n_long > 0 ? long_threshold == kScanMaxRow : p->max_degree <= kScanMaxRow)) {
+    // the row-aligned entry windows of the GAT aggregate's scan (gat_scan.hip): plans asked to cut at its row limit
+    // (Csr.gat_plan) and cut there -- or without a longer row; the aggregation's own plans never pay for them
+    if (long_threshold_arg == kScanMaxRow && p->nnz > 0 && p->nnz < ((int64_t)1 << 30) &&
+        (p->n_long > 0 ? long_threshold == kScanMaxRow : p->max_degree <= kScanMaxRow)) {
         p->n_scan_win = (p->nnz + kScanGranule - 1) / kScanGranule;
         SGX_HIP_CHECK(hipMalloc(&p->scan_win, sizeof(int32_t) * 4 * (size_t)(p->n_scan_win + 1)));
         launched_after_readback = true;

@@ -73,7 +73,7 @@ struct sgx_plan {
     // where the window behind the boundary begins; [4 g + 2], [4 g + 3] = the same pair, or the row before and ITS first
     // entry when that row is a long one (it belongs to the tasks) -- where the window before the boundary ends.  The
     // entry-order form of the GAT aggregate's softmax weights (gat_scan.hip) takes its row-aligned ranges from it; built
-    // for plans that cut at 256 entries (Csr.gat_plan) or hold no longer row, NULL otherwise.
+    // for plans asked to cut at 256 entries (Csr.gat_plan) that do, or hold no longer row; NULL otherwise.
     int32_t *scan_win;     // [4 (n_scan_win + 1)]
     int64_t n_scan_win;
     float natural_utilization;   // share of lane-group steps doing work when rows are packed in natural order
