@@ -377,6 +377,12 @@ int sgx_readout_mean_linear(int dtype, int n_graphs, int F, int C, const void *X
                             const int32_t *graph_ptr, const float *W, const float *bias, float *pooled,
                             float *logits, void *stream);
 
+/* Backward of that pooling for the training step (the autograd of global_mean_pool in MOL cell 18's forward, cell 20's
+ * loop): grad_X[r][:] = grad_pooled[g][:] / (graph_ptr[g+1] - graph_ptr[g]) for the rows r of graph g, written in
+ * `dtype` (the element type of the layer output the pooling read); rows outside every graph are not written. */
+int sgx_readout_mean_backward(int dtype, int n_graphs, int F, const float *grad_pooled, const int32_t *graph_ptr,
+                              void *grad_X, int64_t ldg, void *stream);
+
 /* ReLU backward of RPYNQ (MOL cell 16): grad[i] = (out[i] == 0) ? 0 : grad[i], in place. */
 int sgx_relu_mask_backward(int dtype_out, const void *out, int dtype_grad, void *grad, int64_t n,
                            void *stream);

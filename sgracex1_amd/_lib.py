@@ -29,7 +29,7 @@ SYMBOLS = [
     "sgx_layer_workspace_bytes", "sgx_layer_forward",
     "sgx_spmm_csr", "sgx_spmm_csr_acc", "sgx_spmm_scratch_bytes", "sgx_xw_dense", "sgx_xw_sparse", "sgx_transpose",
     "sgx_gat_aggregate", "sgx_gat_scratch_bytes", "sgx_csr_validate", "sgx_coo_to_csr", "sgx_relu_mask_backward",
-    "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear", "sgx_gat_backward_edges",
+    "sgx_xt_g", "sgx_xt_g_workspace_bytes", "sgx_readout_mean_linear", "sgx_readout_mean_backward", "sgx_gat_backward_edges",
     "sgx_stream_copy", "sgx_xw_dense_act", "sgx_event_create", "sgx_event_destroy", "sgx_event_record", "sgx_event_elapsed_ms",
     "sgx_gat_aggregate_fill", "sgx_col_sums", "sgx_col_sums_scratch_bytes", "sgx_pack_rows",
     "sgx_code_bias", "sgx_quantize_codes_i8", "sgx_xw_dense_i8", "sgx_xw_dense_i8_workspace_bytes",
@@ -159,6 +159,8 @@ def _load():
     lib.sgx_gat_backward_edges.restype = c_int
     lib.sgx_readout_mean_linear.argtypes = [c_int, c_int, c_int, c_int, vp, c_i64, vp, vp, vp, vp, vp, vp]
     lib.sgx_readout_mean_linear.restype = c_int
+    lib.sgx_readout_mean_backward.argtypes = [c_int, c_int, c_int, vp, vp, vp, c_i64, vp]
+    lib.sgx_readout_mean_backward.restype = c_int
     lib.sgx_xt_g_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.sgx_xt_g_workspace_bytes.restype = sz
     lib.sgx_xt_g.argtypes = [c_int, c_int, c_int, c_int, vp, c_i64, vp, c_i64, vp, c_i64, vp, sz, vp]

@@ -234,11 +234,12 @@ class GCN_PYNQ(torch.nn.Module):
         if acc == 1 and not self.training and not torch.is_grad_enabled():
             # inference: pooling and the Linear head in one launch (dropout is the identity in eval);
             # `batch` is sorted (graphs are contiguous), so a graph is a row segment
-            counts = torch.bincount(batch)
-            ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=batch.device)
-            ptr[1:] = torch.cumsum(counts, 0)
-            return ops.readout_mean_linear(x.contiguous(), ptr, self.lin.weight, self.lin.bias)
-        x = x.float()
-        x = global_mean_pool(x, batch)
+            return ops.readout_mean_linear(x.contiguous(), ops.graph_ptr_of(batch), self.lin.weight, self.lin.bias)
+        if acc == 1:
+            # training: the pooling as one launch each way (the same fp32 means as the inference kernel); dropout and
+            # the 64 x 2 head stay torch's
+            x = ops.ReadoutMean.apply(x, ops.graph_ptr_of(batch), batch.numel() == x.shape[0])
+        else:
+            x = global_mean_pool(x.float(), batch)
         x = F.dropout(x, p=0.5, training=self.training)
         return self.lin(x)

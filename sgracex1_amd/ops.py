@@ -673,6 +673,47 @@ def readout_mean_linear(x, graph_ptr, weight=None, bias=None, want_pooled=False)
     return (logits, pooled) if want_pooled else logits
 
 
+def readout_mean_backward(grad_pooled, graph_ptr, n_rows, dtype, covers_all_rows=False):
+    """grad of the rows a global_mean_pool read (sgx_readout_mean_backward): grad_pooled fp32 [n_graphs, F] -> [n_rows, F]
+    in `dtype`, each row its graph's gradient over the graph's size; rows of no graph get 0 (covers_all_rows: the caller
+    knows there are none, e.g. graph_ptr_of(batch), and the result needs no clearing first)."""
+    _dev2d(grad_pooled, "grad_pooled")
+    _dev(graph_ptr, "graph_ptr")
+    g = grad_pooled.float().contiguous()
+    out = (torch.empty if covers_all_rows else torch.zeros)((n_rows, g.shape[1]), dtype=dtype, device=g.device)
+    check(lib.sgx_readout_mean_backward(dtype_code(dtype), graph_ptr.numel() - 1, g.shape[1], _ptr(g), _ptr(graph_ptr), _ptr(out),
+                                        out.stride(0), _stream()), "sgx_readout_mean_backward")
+    return out
+
+
+class ReadoutMean(torch.autograd.Function):
+    """global_mean_pool over contiguous graphs as one launch each way (MOL cell 18's pooling inside the training step):
+    forward = sgx_readout_mean_linear without a head (fp32 means in row order), backward = sgx_readout_mean_backward."""
+
+    @staticmethod
+    def forward(ctx, x, graph_ptr, covers_all_rows=False):
+        ctx.save_for_backward(graph_ptr)
+        ctx.about_x = (x.shape[0], x.dtype, bool(covers_all_rows))
+        return readout_mean_linear(x.contiguous(), graph_ptr)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (graph_ptr,) = ctx.saved_tensors
+        n, dtype, covers = ctx.about_x
+        return readout_mean_backward(grad, graph_ptr, n, dtype, covers), None, None
+
+
+def graph_ptr_of(batch):
+    """graph_ptr [n_graphs + 1] int32 of a sorted PyG `batch` vector, kept on the tensor (an epoch loop passes the same
+    batch every step)."""
+    def build():
+        counts = torch.bincount(batch)
+        ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=batch.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        return ptr
+    return cached_on(batch, ("graph_ptr",), build)
+
+
 def relu_mask_backward_(out, grad):
     """grad[out == 0] = 0 in place (RPYNQ.backward, MOL cell 16)."""
     _dev(out, "out")

@@ -88,6 +88,39 @@ def test_readout_mean_linear_matches_torch(dtype):
     assert torch.equal(pooled[2], torch.zeros(64, device="cuda"))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("F", [64, 7, 300])
+def test_readout_mean_pooling_in_the_training_step(dtype, F):
+    """ops.ReadoutMean (the pooling of MOL cell 18 inside the training step: one launch each way) against
+    global_mean_pool under autograd -- ragged graph sizes, an empty graph, the gradient in the layer output's own type;
+    with rows that belong to no graph the gradient there is 0."""
+    from sgracex1_amd import ops
+    from sgracex1_amd.pyg_lite import global_mean_pool
+    g = torch.Generator(device="cuda")
+    g.manual_seed(F)
+    sizes = torch.tensor([17, 1, 0, 300, 28, 5], device="cuda")
+    batch = torch.repeat_interleave(torch.arange(6, device="cuda"), sizes)
+    n = int(sizes.sum())
+    x = torch.randn((n, F), generator=g, device="cuda").to(dtype).requires_grad_()
+    twin = x.detach().clone().requires_grad_()
+    up = torch.randn((6, F), generator=g, device="cuda")
+    ptr = ops.graph_ptr_of(batch)
+    assert ptr.dtype == torch.int32 and ptr.tolist() == [0, 17, 18, 18, 318, 346, 351] and ops.graph_ptr_of(batch) is ptr
+    got = ops.ReadoutMean.apply(x, ptr, True)
+    want = global_mean_pool(twin.float(), batch, size=6)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    got.backward(up)
+    want.backward(up)
+    assert x.grad.dtype == dtype
+    torch.testing.assert_close(x.grad.float(), twin.grad.float(), rtol=1e-3 if dtype == torch.float16 else 1e-6, atol=1e-6)
+    # a pointer that stops short of the last rows: their gradient is 0, not what the allocator left there
+    short = ptr[:5].contiguous()
+    junk = torch.full((n, F), float("nan"), device="cuda", dtype=dtype)
+    del junk
+    gx = ops.readout_mean_backward(up[:4], short, n, dtype)
+    assert torch.equal(gx[:318], x.grad[:318]) and not gx[318:].any()
+
+
 @pytest.mark.parametrize("F", [7, 16, 64, 256, 300])
 @pytest.mark.parametrize("vdtype", [torch.float16, torch.float32])
 def test_gat_backward_edge_pass_matches_dense_formulas(F, vdtype):
