@@ -769,7 +769,7 @@ __device__ __forceinline__ void alpha_row_in_registers(
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (k >= kmax) break;
-        x[k] = (pos >> k) & 1u ? expf(x[k] - m) : 0.0f;
+        x[k] = (pos >> k) & 1u ? exp_weight(x[k] - m) : 0.0f;
         l += x[k];
     }
 #pragma unroll
@@ -914,11 +914,14 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
         for (int k0 = 0; k0 < KB; k0 += 8) {
             if (k0 >= nm) break;
             unsigned c[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool ok = alone && head_ok && k0 + k < deg;
-                const unsigned off = ok ? (unsigned)(e0 + k0 + k) * 4u : kOOB;
-                c[k] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
+            if constexpr (LH >= 8) {
+                // lane j of a row requests entry k0 + j -- one column and one value instruction per 8 entries, 32 contiguous
+                // bytes per row, instead of one per entry with the row's lanes all on the same address (every such
+                // instruction is 8 rows' lines to look up; the kernel is bound by those look-ups) -- and the row's lanes
+                // take the columns from one another; the live flags of the row's 8 entries come out of one ballot
+                const bool mine = alone && h < 8 && k0 + h < deg;
+                const unsigned off = mine ? (unsigned)(e0 + k0 + h) * 4u : kOOB;
+                const unsigned cm = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
                 float v;
                 if constexpr (sizeof(T) == 2) {
                     const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0);
@@ -926,7 +929,25 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
                 } else {
                     v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
                 }
-                pos |= (ok && v > 0.0f) ? (1u << (k0 + k)) : 0u;
+                const unsigned long long live = __ballot(mine && v > 0.0f);
+                pos |= ((unsigned)(live >> (grp * LH)) & 0xFFu) << k0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = (unsigned)__builtin_amdgcn_ds_bpermute((grp * LH + k) * 4, (int)cm);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool ok = alone && head_ok && k0 + k < deg;
+                    const unsigned off = ok ? (unsigned)(e0 + k0 + k) * 4u : kOOB;
+                    c[k] = __builtin_amdgcn_raw_buffer_load_b32(col_rsrc, off, 0, 0);
+                    float v;
+                    if constexpr (sizeof(T) == 2) {
+                        const unsigned short hb = __builtin_amdgcn_raw_buffer_load_b16(val_rsrc, off >> 1, 0, 0);
+                        v = (float)__builtin_bit_cast(T, hb);
+                    } else {
+                        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(val_rsrc, off, 0, 0));
+                    }
+                    pos |= (ok && v > 0.0f) ? (1u << (k0 + k)) : 0u;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -951,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
             if (k0 >= nm) break;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float p = (pos >> (k0 + k)) & 1u ? expf(x[k0 + k] - m) : 0.0f;
+                const float p = (pos >> (k0 + k)) & 1u ? exp_weight(x[k0 + k] - m) : 0.0f;
                 x[k0 + k] = p;
                 l += p;
             }
@@ -1026,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_rows_heads_kernel(
                     if (k >= kmax) break;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        x[k][q] = (pv >> k) & 1u ? expf(x[k][q] - m[q]) : 0.0f;
+                        x[k][q] = (pv >> k) & 1u ? exp_weight(x[k][q] - m[q]) : 0.0f;
                         l[q] += x[k][q];
                     }
                 }
@@ -1228,7 +1249,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_task_stats_kernel(
                 if (mk[h] == -INFINITY) continue;
                 float sum = l[h] * rescale_factor(m[h], mk[h]);
 #pragma unroll
-                for (int u = 0; u < U; ++u) sum += expf(x[u][h] - mk[h]);           // (a masked entry: exp(-inf) = 0)
+                for (int u = 0; u < U; ++u) sum += exp_weight(x[u][h] - mk[h]);           // (a masked entry: exp(-inf) = 0)
                 l[h] = sum;
                 m[h] = mk[h];
             }
@@ -1297,7 +1318,7 @@ __global__ __launch_bounds__(kBlock) void gat_alpha_long_write_kernel(
             const int j = j0 + 64 * u + lane;
             const int h = pow2 ? (j & (n_heads - 1)) : j % n_heads;        // (the task begins at head 0 of an entry)
             const float m = tm[h], l = tl[h];
-            if (j < n) Wt[j] = l > 0.0f ? expf(x[u] - m) * (1.0f / l) : 0.0f;     // (the expression of gat_weighted_kernel's from_scores)
+            if (j < n) Wt[j] = l > 0.0f ? exp_weight(x[u] - m) * (1.0f / l) : 0.0f;     // (the expression of gat_weighted_kernel's from_scores)
         }
     }
 }
@@ -1348,7 +1369,7 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
                 c = (unsigned)__builtin_nontemporal_load(col + idx);
                 if (!HEADS) {
                     a = __builtin_nontemporal_load(W + idx);
-                    if constexpr (XF) a = xinv > 0.0f ? expf(a - xm) * xinv : 0.0f;
+                    if constexpr (XF) a = xinv > 0.0f ? exp_weight(a - xm) * xinv : 0.0f;
                 }
             }
         };
@@ -1369,7 +1390,7 @@ __global__ __launch_bounds__(kBlock) void gat_weighted_kernel(
                     if (HEADS) {
                         aa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                  wsrc, t < n ? ((unsigned)(base + t) * (unsigned)n_heads + my_head) * 4u : kOOB, 0, 0));
-                        if constexpr (XF) aa = (t < n && xinv > 0.0f) ? expf(aa - xm) * xinv : 0.0f;
+                        if constexpr (XF) aa = (t < n && xinv > 0.0f) ? exp_weight(aa - xm) * xinv : 0.0f;
                     } else {
                         aa = __shfl(a, t, LPR);
                     }

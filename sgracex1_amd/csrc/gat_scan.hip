@@ -207,7 +207,7 @@ __device__ __forceinline__ void scan_range(
                 float carry = 0.0f;
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const float p = (pos >> k) & 1u ? expf(x[k][h] - tot[k]) : 0.0f;
+                    const float p = (pos >> k) & 1u ? exp_weight(x[k][h] - tot[k]) : 0.0f;
                     x[k][h] = p;
                     float v = seg_scan<AddOp>(p, where[k] & 255, lane);
                     v = (cont >> k) & 1u ? v + carry : v;
