@@ -59,18 +59,6 @@ __global__ __launch_bounds__(kBlock) void gat_scores_kernel(int n_rows, int n_fe
     if (r < n_rows && sub == 0) { s1[r] = p1; s2[r] = p2; }
 }
 
-// ReLU (SG.py:660-661), then the quantised layer's deq_o factor on fp32 outputs (SG.py:666-667; 0 = off)
-template <typename T>
-__device__ __forceinline__ T gat_finish(float sum, int relu, float out_scale)
-{
-    T v = Elem<T>::from_f32(sum);
-    v = (!relu || v > (T)0) ? v : (T)0;
-    if constexpr (sizeof(T) == 4) {
-        if (out_scale != 0.0f) v = v * out_scale;
-    }
-    return v;
-}
-
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void gat_aggregate_kernel(
     int n_rows, int n_cols, int n_feat, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -1666,6 +1654,36 @@ int gat_two_stage(const GatArgs &a)
     const int ldp = (int)sgx_align_up((size_t)a.n_feat, 4);
     float *pacc = a.split, *pm = pacc + (size_t)p->n_tasks * ldp, *pl = pm + (size_t)p->n_tasks * a.n_heads;
     float *row_m = pl + (size_t)p->n_tasks * a.n_heads, *row_l = row_m + (size_t)p->n_long * a.n_heads;
+    const int dtype_code = sizeof(T) == 2 ? SGX_F16 : SGX_F32;
+    // One walk pays while a head spans few lanes -- every lane of a head forms the piece's 8 scores and exponentials itself, and
+    // a head wider than a DPP row half sums its dots through LDS permutes (measured, tools/gat_probe.py: 8 heads x 32 columns
+    // 0.286 -> 0.234 ms on the arxiv shape, one head of 64 columns 0.80 -> 0.70 ms and 8 heads 1.94 -> 0.74 ms on a 29 M-entry
+    // R-MAT graph, 2 heads x 128 columns = 16 lanes 0.252 -> 0.230 ms; one head of 256 columns = 32 lanes 0.235 -> 0.254 ms: the
+    // two stages stay).  SGX_GAT_FUSED = 0 / 2: never / wherever it applies.
+    const int lanes_of_a_head = (a.n_feat / a.n_heads) / (VEC > 0 ? VEC : 1);
+    const bool fused_pays = sgx_tune().gat_fused == 2 || (sgx_tune().gat_fused == 1 && lanes_of_a_head <= 16);
+    if (!a.E && !a.S && fused_pays && VEC == Elem<T>::kVec && a.vec_ok && sgx_gat_fused_applicable(dtype_code, a.n_feat, a.n_heads, LPR)) {
+        // no side outputs wanted: one walk over the rows, the neighbours' scores formed from the rows it gathers (gat_fused.hip)
+        sgx_gat_fused_args f{};
+        f.dtype = dtype_code; f.lpr = LPR; f.relu = a.relu; f.n_feat = a.n_feat; f.n_heads = a.n_heads;
+        f.n_work = p->row_order ? p->n_ordered : a.n_rows;
+        f.long_threshold = thr; f.vec_store = a.vec_store; f.n_tasks = thr > 0 ? p->n_tasks : 0; f.ldp = ldp;
+        f.alpha = a.alpha; f.out_scale = a.out_scale;
+        f.rowptr = a.rowptr; f.col = a.col; f.row_order = p->row_order;
+        f.task_row = p->task_row; f.task_e0 = p->task_e0; f.task_e1 = p->task_e1;
+        f.val = a.val; f.Wh = a.Wh; f.att = a.att; f.h_bytes = a.h_bytes; f.ld_bytes = a.ld_bytes;
+        f.s1 = s1; f.fill = a.fill; f.D = a.D; f.ldd = a.ldd; f.pacc = pacc; f.pm = pm; f.pl = pl; f.stream = a.stream;
+        const int rc = sgx_gat_fused(f);
+        if (rc != SGX_OK) return rc;
+        if (f.n_tasks > 0) {
+            const int64_t total = (int64_t)p->n_long * a.n_feat;
+            hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                               a.stream, p->n_long, a.n_feat, a.n_heads, f_head, p->long_row, p->long_first, pacc, ldp, pm, pl,
+                               (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
+            SGX_LAUNCH_CHECK();
+        }
+        return SGX_OK;
+    }
     float *W = a.S ? a.S : a.two_stage;
     unsigned char *dead = reinterpret_cast<unsigned char *>(a.two_stage + (size_t)p->nnz * a.n_heads);
     int rc;

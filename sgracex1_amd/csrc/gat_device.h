@@ -19,6 +19,18 @@ __device__ __forceinline__ float exp_weight(float x) { return __builtin_amdgcn_e
 __device__ __forceinline__ float exp_weight(float x) { return expf(x); }
 #endif
 
+// ReLU (SG.py:660-661), then the quantised layer's deq_o factor on fp32 outputs (SG.py:666-667; 0 = off)
+template <typename T>
+__device__ __forceinline__ T gat_finish(float sum, int relu, float out_scale)
+{
+    T v = Elem<T>::from_f32(sum);
+    v = (!relu || v > (T)0) ? v : (T)0;
+    if constexpr (sizeof(T) == 4) {
+        if (out_scale != 0.0f) v = v * out_scale;
+    }
+    return v;
+}
+
 // merge two online-softmax states (m, l); (-inf, 0) is the empty state
 __device__ __forceinline__ void softmax_merge(float &m, float &l, float m2, float l2)
 {

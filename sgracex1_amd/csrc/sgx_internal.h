@@ -25,6 +25,7 @@ typedef _Float16 f16;
 // variable afterwards (tests and probes that compare two forms in one process) calls sgx_reload_env().
 struct sgx_tuning {
     bool gat_one_pass, gat_no_fused_scores;
+    int gat_fused;             // SGX_GAT_FUSED: without E / S outputs the aggregate as one walk (gat_fused.hip): 0 = never, 1 = by shape (default), 2 = wherever it applies
     int gat_scan;              // SGX_GAT_SCAN: 0 = the GAT aggregate's short rows never in entry order, 1 = by shape (default), 2 = always
     bool xw_no_wlds, xw_no_stationary_f32, xw_sparse_no_lds, xw_short_tiles, xw_no_lds;
     bool xtg_scalar, xtg_wave_tiles;
@@ -162,6 +163,22 @@ bool sgx_gat_scan_applicable(const sgx_plan *plan);
 int sgx_gat_alpha_scan(int dtype, int n_rows, int n_heads, const sgx_plan *plan, const int32_t *rowptr, const int32_t *col,
                        const void *val, const float *s1, const float *s2, float alpha, float *W, float *E, unsigned char *dead,
                        hipStream_t stream);
+
+// gat_fused.hip: the GAT aggregate in one walk, the neighbours' scores formed from the rows it gathers (no E / S outputs)
+struct sgx_gat_fused_args {
+    int dtype, lpr, relu, n_work, n_feat, n_heads, long_threshold, vec_store, n_tasks, ldp;
+    float alpha, out_scale;
+    const int32_t *rowptr, *col, *row_order, *task_row, *task_e0, *task_e1;
+    const void *val, *Wh, *att;
+    unsigned h_bytes, ld_bytes;
+    const float *s1, *fill;
+    void *D;
+    int64_t ldd;
+    float *pacc, *pm, *pl;
+    hipStream_t stream;
+};
+bool sgx_gat_fused_applicable(int dtype, int n_feat, int n_heads, int lpr);
+int sgx_gat_fused(const sgx_gat_fused_args &a);
 
 // GAT layer: the attention scores formed by the X.W kernel's epilogue (fp16, heads of 32 columns, two-stage aggregate)
 bool sgx_gat_scores_fusable(int dtype, int n_feat, int n_heads, const sgx_plan *plan);

@@ -284,6 +284,7 @@ void load_tuning()
     t.gat_one_pass = flag("SGX_GAT_ONE_PASS");
     t.gat_no_fused_scores = flag("SGX_GAT_NO_FUSED_SCORES");
     { const char *v = getenv("SGX_GAT_SCAN"); t.gat_scan = v ? atoi(v) : 1; }
+    { const char *v = getenv("SGX_GAT_FUSED"); t.gat_fused = v ? atoi(v) : 1; }
     t.xw_no_wlds = flag("SGX_XW_NO_WLDS");
     t.xw_no_stationary_f32 = flag("SGX_XW_NO_STATIONARY_F32");
     t.xw_sparse_no_lds = flag("SGX_XW_SPARSE_NO_LDS");

@@ -343,8 +343,15 @@ def test_gat_long_rows_take_the_split_path(sgx, oracle, dtype, F):
                                       fill_dead_rows=False, use_plan=False)
     np.testing.assert_allclose(got.float().cpu().numpy(), plain.float().cpu().numpy(), **tol)
     assert torch.equal(gE, pE)
+    # without the side outputs the one-walk form runs (csrc/gat_fused.hip): its own rounding, the same bits every run
+    # (fixed merge order), and the two-stage form's bits when that is asked for
     again = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, fill_dead_rows=False)
-    assert torch.equal(again, got)                                         # fixed merge order: same bits every run
+    assert torch.equal(again, sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, fill_dead_rows=False))
+    np.testing.assert_allclose(again.float().cpu().numpy(), D, **tol)
+    assert (again[1500] == 0).all()
+    from sgracex1_amd import _lib
+    with _lib.tuning(SGX_GAT_FUSED="0"):
+        assert torch.equal(sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=1, fill_dead_rows=False), got)
     filled = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att, dtype), relu=0)          # dense-emulation rule for the masked hub
     np.testing.assert_allclose(filled[1500].float().cpu().numpy(), Wh.mean(0), **tol)
 
@@ -389,7 +396,11 @@ def test_gat_multi_head_long_rows(sgx, oracle, dtype, heads, f_head):
                               use_plan=False)
     np.testing.assert_allclose(got.float().cpu().numpy(), plain.float().cpu().numpy(), rtol=tol["rtol"], atol=max(tol["atol"], 1e-5))
     again = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads, fill_dead_rows=False)
-    assert torch.equal(again, got)
+    assert torch.equal(again, sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads, fill_dead_rows=False))
+    np.testing.assert_allclose(again.float().cpu().numpy(), got.float().cpu().numpy(), rtol=tol["rtol"], atol=max(tol["atol"], 1e-5))
+    from sgracex1_amd import _lib
+    with _lib.tuning(SGX_GAT_FUSED="0"):
+        assert torch.equal(sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=1, heads=heads, fill_dead_rows=False), got)
     filled = sgx.gat_aggregate(A, _dev(Wh, dtype), _dev(att.reshape(-1), dtype), relu=0, heads=heads)
     np.testing.assert_allclose(filled[2400].float().cpu().numpy(), Wh.mean(0), **tol)
 
@@ -694,7 +705,9 @@ def test_gat_two_stage_with_and_without_edge_outputs(oracle, dtype, heads, F, ge
     att = (torch.randn(heads * 2 * (F // heads), generator=g, device="cuda") * (0.5 / (F // heads) ** 0.5)).to(dtype)
     junk = torch.full((20_000_000,), float("nan"), device="cuda")              # what the allocator hands out next is not zeros
     del junk
-    fly = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
+    from sgracex1_amd import _lib
+    with _lib.tuning(SGX_GAT_FUSED="0"):          # (without side outputs the default is the one-walk form: tests/test_gpu_gat_fused.py)
+        fly = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
     with_edges, _E, S = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads, want_edge_outputs=True)
     assert torch.equal(fly, with_edges)
     # rows without a live edge receive the mean row of Wh (the dense emulation's rule, SG.py:638-641) -- every one of
@@ -786,6 +799,11 @@ def test_gat_layer_scores_from_the_product_epilogue(M, P, heads, gen_name):
         plain, E0, S0 = ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads, want_edge_outputs=True)
     assert torch.equal(fused, plain) and torch.equal(E, E0) and torch.equal(S, S0)
     Wh = ops.xw_dense(X, Wt)
-    composed = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
+    with _lib.tuning(SGX_GAT_FUSED="0"):
+        composed = ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads)
     assert torch.equal(fused, composed)
     assert torch.isfinite(fused.float()).all()
+    # without side outputs the aggregate may be the one-walk form (csrc/gat_fused.hip), which takes s1 from the same place:
+    # the layer and the composition agree bit for bit there too
+    assert torch.equal(ops.layer_forward(A, X, Wt, relu=True, gat_attention=att, gat_heads=heads),
+                       ops.gat_aggregate(A, Wh, att, alpha=0.2, relu=True, heads=heads))

@@ -4,7 +4,8 @@ tuned on, a few launches each -- for `rocprofv3 --kernel-trace --stats` (per-ker
 
     python3 tools/gat_probe.py [arxiv|arxiv-rmat|rmat20] [--heads 1|8] [--launches 20]
 
-SGX_GAT_SCAN=0 / 2 in the environment: stage A's short rows never / always in entry order (gat_scan.hip; default: by shape).
+SGX_GAT_SCAN=0 / 2 in the environment: stage A's short rows never / always in entry order (gat_scan.hip; default: by shape);
+SGX_GAT_FUSED=0 / 2: the one-walk form (gat_fused.hip) never / wherever it applies (default: heads of up to 8 lanes).
 """
 import argparse
 import json
@@ -23,6 +24,7 @@ def main():
     ap.add_argument("shape", nargs="?", default="arxiv")
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--width", type=int, default=0, help="columns of Wh (default: 256 on the arxiv shapes, 64 on rmat20)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     if a.shape == "arxiv":
@@ -31,6 +33,7 @@ def main():
         A, P = graphs.rmat_graph_n(169_343, 2_330_000, seed=5, device=dev), 256
     else:
         A, P = graphs.rmat_graph(20, 30_000_000, seed=5, device=dev), 64
+    P = a.width or P
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     Wh = torch.rand((A.n_rows, P), generator=g, device=dev).half()
