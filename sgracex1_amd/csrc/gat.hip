@@ -1671,18 +1671,10 @@ int gat_two_stage(const GatArgs &a)
         f.alpha = a.alpha; f.out_scale = a.out_scale;
         f.rowptr = a.rowptr; f.col = a.col; f.row_order = p->row_order;
         f.task_row = p->task_row; f.task_e0 = p->task_e0; f.task_e1 = p->task_e1;
+        f.long_row = p->long_row; f.long_first = p->long_first; f.n_long = p->n_long; f.n_multi = p->n_multi;
         f.val = a.val; f.Wh = a.Wh; f.att = a.att; f.h_bytes = a.h_bytes; f.ld_bytes = a.ld_bytes;
         f.s1 = s1; f.fill = a.fill; f.D = a.D; f.ldd = a.ldd; f.pacc = pacc; f.pm = pm; f.pl = pl; f.stream = a.stream;
-        const int rc = sgx_gat_fused(f);
-        if (rc != SGX_OK) return rc;
-        if (f.n_tasks > 0) {
-            const int64_t total = (int64_t)p->n_long * a.n_feat;
-            hipLaunchKernelGGL((gat_split_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                               a.stream, p->n_long, a.n_feat, a.n_heads, f_head, p->long_row, p->long_first, pacc, ldp, pm, pl,
-                               (T *)a.D, a.ldd, a.relu, a.fill, row_m, row_l, a.out_scale);
-            SGX_LAUNCH_CHECK();
-        }
-        return SGX_OK;
+        return sgx_gat_fused(f);
     }
     float *W = a.S ? a.S : a.two_stage;
     unsigned char *dead = reinterpret_cast<unsigned char *>(a.two_stage + (size_t)p->nnz * a.n_heads);

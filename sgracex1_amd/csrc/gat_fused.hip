@@ -9,8 +9,8 @@
 // registers, and the softmax costs no memory traffic at all.  exp is the hardware's v_exp_f32 on (x - max) log2(e) --
 // relative error about (2 + |x|) 2^-24 on a weight that only ever reaches the caller inside the 16- or 32-bit sums of D.
 // Rows over the plan's cut: a wavefront per task with a state per lane group, merged over the groups, the tasks of a row
-// merged in task order by gat.hip's gat_split_finalize_kernel (the same (pacc, pm, pl) layout as its one-pass form).
-// Same schedule as gat_weighted_kernel otherwise: degree order where the plan has one, long rows through tasks.
+// merged in task order by gat_fused_finalize_kernel.  Same schedule as gat_weighted_kernel otherwise: degree order where
+// the plan has one (its one-piece tail 64 rows per wavefront), long rows through tasks.
 // Rows without a live entry give `fill` (the dense emulation's mean row, SG.py:638-641) or 0.
 #include "gat_device.h"
 
@@ -26,11 +26,6 @@ __device__ __forceinline__ float dpp_swap(float v)
 template <int HL>
 __device__ __forceinline__ float head_sum(float v, int lane)
 {
-#if defined(SGX_FUSED_DBG) && (SGX_FUSED_DBG & 4)
-#pragma unroll
-    for (int off = 1; off < HL; off <<= 1) v += __shfl_xor(v, off);
-    return v;
-#endif
     if constexpr (HL >= 2) v += dpp_swap<0xB1>(v);           // quad_perm [1,0,3,2]
     if constexpr (HL >= 4) v += dpp_swap<0x4E>(v);           // quad_perm [2,3,0,1]
     if constexpr (HL >= 8) v += dpp_swap<0x141>(v);          // row_half_mirror: the other quad of the 8
@@ -40,24 +35,13 @@ __device__ __forceinline__ float head_sum(float v, int lane)
     return v;
 }
 
-#if defined(SGX_FUSED_DBG) && (SGX_FUSED_DBG & 2)
-__device__ __forceinline__ float exp2_of(float y) { return expf(y); }
-#else
 __device__ __forceinline__ float exp2_of(float y) { return __builtin_amdgcn_exp2f(y * 1.44269504088896340736f); }
-#endif
 
 // sum_i frag[i] * (element i of the 16 gathered bytes)
 template <typename T, int VEC> struct Dot;
 template <> struct Dot<f16, 8> {
     static __device__ __forceinline__ float run(const float *frag, u32x4 raw)
     {
-#if defined(SGX_FUSED_DBG) && (SGX_FUSED_DBG & 1)
-        union { u32x4 v; f16 h[8]; } u; u.v = raw;
-        float dd = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dd = __builtin_fmaf(frag[i], (float)u.h[i], dd);
-        return dd;
-#endif
         float d = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -79,6 +63,10 @@ template <> struct Dot<float, 4> {
     }
 };
 
+#ifndef SGX_GAT_FUSED_WAVES
+#define SGX_GAT_FUSED_WAVES 1      // (a launch bound of 5 wavefronts per SIMD = 96 registers: no gain measured)
+#endif
+
 template <int VEC> struct SoftState {
     float m, l, acc[VEC];
     __device__ __forceinline__ void clear()
@@ -90,14 +78,52 @@ template <int VEC> struct SoftState {
     }
 };
 
-template <typename T, int VEC, int LPR, int HL>
-__global__ __launch_bounds__(kBlock) void gat_fused_kernel(
+// UNR entries of a piece -- entry T0 + u held by lane T0 + u of the lane group (column C, bit T0 + u of LIVE), N entries in
+// the piece -- folded into the state ST of the lane's head: gather, score from the gathered row, rescale, accumulate.
+// (Text, not a function: as an inlined function or lambda the same statements cost the row walk 7 more registers -- 102
+// instead of 95, a wavefront per SIMD -- and 8 % on a uniform graph.)
+// The s_nop: v_exp_f32 is a transcendental, its result needs a wait state before another VALU instruction reads it.  hipcc
+// inserts that for its own instructions and does not look inside the inline assembly of Fma<f16>, whose first
+// v_fma_mix_f32 then read the weight before it was there (the lane's first column, in the lanes the quarter-rate unit
+// serves first: wrong sums, NaNs on partial pieces).
+#define SGX_GAT_FOLD(ST, SI, C, LIVE, N, T0)                                                                                       \
+    do {                                                                                                                             \
+        u32x4 raw_[UNR];                                                                                                             \
+        _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                                            \
+            const int t_ = (T0) + u;                                                                                                 \
+            const unsigned cc_ = (unsigned)__shfl((int)(C), t_, LPR);                                                                \
+            raw_[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (t_ < (N) && col_off != kOOB) ? cc_ * ld_bytes + col_off : kOOB, 0, 0); \
+        }                                                                                                                            \
+        float x_[UNR];                                                                                                               \
+        float mp_ = (ST).m;                                                                                                          \
+        _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                                            \
+            const float d_ = head_sum<HL>(Dot<T, VEC>::run(a2, raw_[u]), lane);                                                      \
+            const bool lv_ = (T0) + u < (N) && (((LIVE) >> ((T0) + u)) & 1ull);                                                      \
+            x_[u] = lv_ ? leaky((SI) + d_, alpha) : -INFINITY;                                                                       \
+            mp_ = fmaxf(mp_, x_[u]);                                                                                                 \
+        }                                                                                                                            \
+        const float ref_ = mp_ == -INFINITY ? 0.0f : mp_; /* (no live entry so far: every exponential below is 0) */                 \
+        const float scale_ = exp2_of((ST).m - ref_);                                                                                 \
+        float sum_ = (ST).l * scale_;                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < VEC; ++i)(ST).acc[i] *= scale_;                                                        \
+        _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                                            \
+            float p_ = exp2_of(x_[u] - ref_);                                                                                        \
+            asm volatile("s_nop 1" : "+v"(p_));                                                                                      \
+            sum_ += p_;                                                                                                              \
+            Fma<T, VEC>::run((ST).acc, p_, raw_[u]);                                                                                 \
+        }                                                                                                                            \
+        (ST).l = sum_;                                                                                                               \
+        (ST).m = mp_;                                                                                                                \
+    } while (0)
+
+template <typename T, int VEC, int LPR, int HL, bool SHORT>
+__global__ __launch_bounds__(kBlock, SGX_GAT_FUSED_WAVES) void gat_fused_kernel(
     int n_work, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
     const T *__restrict__ val, const T *__restrict__ Wh, unsigned h_bytes, unsigned ld_bytes, const T *__restrict__ att,
     const float *__restrict__ s1, float alpha, T *__restrict__ D, int64_t ldd, int relu, float out_scale, int long_threshold,
     int vec_store, const int32_t *__restrict__ row_order, int split_blocks, int n_tasks, const int32_t *__restrict__ task_row,
     const int32_t *__restrict__ task_e0, const int32_t *__restrict__ task_e1, float *__restrict__ pacc, int ldp,
-    float *__restrict__ pm, float *__restrict__ pl, const float *__restrict__ fill)
+    float *__restrict__ pm, float *__restrict__ pl, const float *__restrict__ fill, int n_multi, int short_first)
 {
     constexpr int RPW = 64 / LPR;
     constexpr int UNR = LPR < 8 ? LPR : 8;
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(
     for (int i = 0; i < VEC; ++i)
         a2[i] = (mine && col0 + i < n_feat) ? Elem<T>::to_f32(att[(int64_t)my_head * 2 * f_head + f_head + (col0 - my_head * f_head) + i]) : 0.0f;
 
-    // entries [e0, e1) taken `stride` apart in pieces of LPR, folded into the state of the lane's head
+    // entries [e0, e1) taken `stride` apart in pieces of LPR
     auto walk = [&](SoftState<VEC> &st, float si, int e0, int e1, int stride) {
         unsigned c_next = 0;
         bool v_next = false;
@@ -136,44 +162,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(
 #pragma unroll 1
             for (int t0 = 0; t0 < LPR; t0 += UNR) {
                 if (t0 >= n) break;
-                u32x4 raw[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int t = t0 + u;
-                    const unsigned cc = (unsigned)__shfl((int)c, t, LPR);
-                    raw[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (t < n && col_off != kOOB) ? cc * ld_bytes + col_off : kOOB, 0, 0);
-                }
-                float x[UNR];
-                float mp = st.m;
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const float d = head_sum<HL>(Dot<T, VEC>::run(a2, raw[u]), lane);
-                    const bool lv = t0 + u < n && ((live >> (t0 + u)) & 1ull);
-                    x[u] = lv ? leaky(si + d, alpha) : -INFINITY;
-                    mp = fmaxf(mp, x[u]);
-                }
-                const float ref = mp == -INFINITY ? 0.0f : mp;                        // (no live entry so far: every exponential below is 0)
-                const float scale = exp2_of(st.m - ref);
-                float sum = st.l * scale;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) st.acc[i] *= scale;
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    float p = exp2_of(x[u] - ref);
-                    // v_exp_f32 is a transcendental: its result needs a wait state before another VALU instruction reads it.
-                    // hipcc inserts that for its own instructions and does not look inside the inline assembly of Fma<f16>,
-                    // whose first v_fma_mix_f32 then read the weight before it was there (the lane's first column, in the
-                    // lanes the quarter-rate unit serves first: wrong sums, NaNs on partial pieces)
-                    asm volatile("s_nop 1" : "+v"(p));
-                    sum += p;
-#if defined(SGX_FUSED_DBG) && (SGX_FUSED_DBG & 8)
-                    if constexpr (sizeof(T) == 2) FmaPlainF16::run(st.acc, p, raw[u]); else Fma<T, VEC>::run(st.acc, p, raw[u]);
-#else
-                    Fma<T, VEC>::run(st.acc, p, raw[u]);
-#endif
-                }
-                st.l = sum;
-                st.m = mp;
+                SGX_GAT_FOLD(st, si, c, live, n, t0);
             }
         }
     };
@@ -225,8 +214,52 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(
         }
         return;
     }
+    if constexpr (SHORT && LPR >= 8) {
+        // the degree order's tail of one-piece rows (at most 8 entries), 64 rows per wavefront: row ids, row pointers and the
+        // (column, value) pieces of 64 rows are one round trip each instead of one per 64 / LPR rows (spmm_csr.hip's
+        // spmm_short_rows, gat_weighted_kernel's SHORT); a row is one fold
+        if ((int)blockIdx.x >= short_first) {
+            const int64_t i0 = (int64_t)n_multi + ((int64_t)((int)blockIdx.x - short_first) * (kBlock / 64) + (threadIdx.x >> 6)) * 64;
+            if (i0 >= n_work) return;
+            const int64_t idx = i0 + lane;
+            const bool valid = idx < n_work;
+            const int rid = row_order[valid ? idx : (int64_t)n_work - 1];
+            const int re0 = rowptr[rid];
+            const int rdeg = valid ? rowptr[rid + 1] - re0 : 0;                      // at most 8 (the order's last buckets)
+            constexpr int CH = 4;                        // rows per lane group and batch of requests
+            for (int it0 = 0; it0 < LPR; it0 += CH) {
+                unsigned c[CH];
+                unsigned live[CH];                       // (a row of the tail has at most 8 entries: 8 bits)
+                float si[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int s = (it0 + i) * RPW + grp;
+                    const int se0 = __shfl(re0, s), sdeg = __shfl(rdeg, s);
+                    const int e = sub < sdeg ? se0 + sub : 0;                        // (unconditional loads: slots past the row read entry 0, masked at use)
+                    c[i] = (unsigned)__builtin_nontemporal_load(col + e);
+                    const bool lv = sub < sdeg && Elem<T>::to_f32(__builtin_nontemporal_load(val + e)) > 0.0f;
+                    live[i] = (unsigned)(__ballot(lv) >> (grp * LPR)) & 0xFFu;
+                    si[i] = s1[(int64_t)__shfl(rid, s) * n_heads + my_head];
+                }
+#pragma unroll
+                for (int it = 0; it < CH; ++it) {
+                    const int s = (it0 + it) * RPW + grp;
+                    const int sdeg = __shfl(rdeg, s);
+                    const int64_t rr = __shfl(rid, s);                               // (every lane takes part: a shuffle inside the
+                    const bool row_ok = __shfl((int)valid, s) != 0;                  //  branch below would read lanes that are not in it)
+                    SoftState<VEC> st;
+                    st.clear();
+                    SGX_GAT_FOLD(st, si[it], c[it], (unsigned long long)live[it], sdeg, 0);
+                    if (row_ok) finish_row(st, rr);
+                }
+            }
+            return;
+        }
+        n_work = n_multi;                    // the walk below takes the rows of two pieces and more
+    }
+    const int row_grid = (SHORT ? short_first : (int)gridDim.x) - split_blocks;
     const int64_t wave = (int64_t)((int)blockIdx.x - split_blocks) * (kBlock / 64) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)((int)gridDim.x - split_blocks) * (kBlock / 64);
+    const int64_t n_waves = (int64_t)row_grid * (kBlock / 64);
     for (int64_t r0 = wave * RPW; r0 < n_work; r0 += n_waves * RPW) {
         int64_t r = r0 + grp;
         int e0 = 0, e1 = 0;
@@ -246,19 +279,87 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(
     }
 }
 
+// the tasks of a long row merged in task order: m = max m_t, l = sum l_t 2^((m_t - m) log2 e), row = the same sum over the
+// partial rows, / l -- a thread per (long row, column), eight tasks' states requested at a time (a hub row of a plan cut
+// at 256 entries has hundreds of tasks: one dependent load after the other took 117 us on a 29 M-entry R-MAT graph)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gat_fused_finalize_kernel(
+    int n_long, int n_feat, int n_heads, int f_head, const int32_t *__restrict__ long_row, const int32_t *__restrict__ long_first,
+    const float *__restrict__ pacc, int ldp, const float *__restrict__ pm, const float *__restrict__ pl, T *__restrict__ D,
+    int64_t ldd, int relu, const float *__restrict__ fill, float out_scale)
+{
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (int64_t)n_long * n_feat) return;
+    const int i = (int)(gid / n_feat), j = (int)(gid % n_feat);
+    const int h = j / f_head;
+    const int t0 = long_first[i], t1 = long_first[i + 1];
+    float m = -INFINITY;
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pm[(int64_t)(t + u) * n_heads + h];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    }
+    for (; t < t1; ++t) m = fmaxf(m, pm[(int64_t)t * n_heads + h]);
+    const float ref = m == -INFINITY ? 0.0f : m;
+    float l = 0.0f, a = 0.0f;
+    for (t = t0; t + 8 <= t1; t += 8) {
+        float vm[8], vl[8], va[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            vm[u] = pm[(int64_t)(t + u) * n_heads + h];
+            vl[u] = pl[(int64_t)(t + u) * n_heads + h];
+            va[u] = pacc[(int64_t)(t + u) * ldp + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = exp2_of(vm[u] - ref);
+            l += vl[u] * w;
+            a += va[u] * w;
+        }
+    }
+    for (; t < t1; ++t) {
+        const float w = exp2_of(pm[(int64_t)t * n_heads + h] - ref);
+        l += pl[(int64_t)t * n_heads + h] * w;
+        a += pacc[(int64_t)t * ldp + j] * w;
+    }
+    const float out = l > 0.0f ? a / l : (fill ? fill[j] : 0.0f);
+    D[(int64_t)long_row[i] * ldd + j] = gat_finish<T>(out, relu, out_scale);
+}
+
 template <typename T, int VEC, int LPR, int HL>
 int launch_fused(const sgx_gat_fused_args &a)
 {
     const int rows_per_block = (64 / LPR) * (kBlock / 64);
     const int split_blocks = (a.n_tasks + kBlock / 64 - 1) / (kBlock / 64);
-    int64_t row_blocks = ((int64_t)a.n_work + rows_per_block - 1) / rows_per_block;
+    // the one-piece tail of a degree order 64 rows per wavefront (as the plain aggregation does, spmm_csr.hip)
+    const bool short_tail = LPR >= 8 && a.row_order && !sgx_tune().spmm_no_short_tail && a.n_multi >= 0 && a.n_multi < a.n_work &&
+                            a.n_work - a.n_multi >= 4096;
+    const int n_multi = short_tail ? a.n_multi : a.n_work;
+    const int64_t short_blocks = short_tail ? ((int64_t)(a.n_work - n_multi) + 64 * (kBlock / 64) - 1) / (64 * (kBlock / 64)) : 0;
+    int64_t row_blocks = ((int64_t)n_multi + rows_per_block - 1) / rows_per_block;
     if (row_blocks > 256 * 512) row_blocks = 256 * 512;
-    hipLaunchKernelGGL((gat_fused_kernel<T, VEC, LPR, HL>), dim3((unsigned)(split_blocks + row_blocks)), dim3(kBlock), 0, a.stream,
-                       a.n_work, a.n_feat, a.n_heads, a.n_feat / a.n_heads, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh,
-                       a.h_bytes, a.ld_bytes, (const T *)a.att, a.s1, a.alpha, (T *)a.D, a.ldd, a.relu, a.out_scale,
-                       a.long_threshold, a.vec_store, a.row_order, split_blocks, a.n_tasks, a.task_row, a.task_e0, a.task_e1,
-                       a.pacc, a.ldp, a.pm, a.pl, a.fill);
+    const dim3 grid((unsigned)(split_blocks + row_blocks + short_blocks));
+    const int short_first = (int)(split_blocks + row_blocks);
+#define SGX_GAT_FUSED_LAUNCH(SHORT_)                                                                                             \
+    hipLaunchKernelGGL((gat_fused_kernel<T, VEC, LPR, HL, SHORT_>), grid, dim3(kBlock), 0, a.stream, a.n_work, a.n_feat, a.n_heads,  \
+                       a.n_feat / a.n_heads, a.rowptr, a.col, (const T *)a.val, (const T *)a.Wh, a.h_bytes, a.ld_bytes,             \
+                       (const T *)a.att, a.s1, a.alpha, (T *)a.D, a.ldd, a.relu, a.out_scale, a.long_threshold, a.vec_store,        \
+                       a.row_order, split_blocks, a.n_tasks, a.task_row, a.task_e0, a.task_e1, a.pacc, a.ldp, a.pm, a.pl, a.fill,   \
+                       n_multi, short_first)
+    if (short_tail) SGX_GAT_FUSED_LAUNCH(true);
+    else SGX_GAT_FUSED_LAUNCH(false);
+#undef SGX_GAT_FUSED_LAUNCH
     SGX_LAUNCH_CHECK();
+    if (a.n_tasks > 0) {
+        const int64_t total = (int64_t)a.n_long * a.n_feat;
+        hipLaunchKernelGGL((gat_fused_finalize_kernel<T>), dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, a.stream,
+                           a.n_long, a.n_feat, a.n_heads, a.n_feat / a.n_heads, a.long_row, a.long_first, a.pacc, a.ldp, a.pm, a.pl,
+                           (T *)a.D, a.ldd, a.relu, a.fill, a.out_scale);
+        SGX_LAUNCH_CHECK();
+    }
     return SGX_OK;
 }
 

@@ -166,9 +166,9 @@ int sgx_gat_alpha_scan(int dtype, int n_rows, int n_heads, const sgx_plan *plan,
 
 // gat_fused.hip: the GAT aggregate in one walk, the neighbours' scores formed from the rows it gathers (no E / S outputs)
 struct sgx_gat_fused_args {
-    int dtype, lpr, relu, n_work, n_feat, n_heads, long_threshold, vec_store, n_tasks, ldp;
+    int dtype, lpr, relu, n_work, n_feat, n_heads, long_threshold, vec_store, n_tasks, ldp, n_long, n_multi;
     float alpha, out_scale;
-    const int32_t *rowptr, *col, *row_order, *task_row, *task_e0, *task_e1;
+    const int32_t *rowptr, *col, *row_order, *task_row, *task_e0, *task_e1, *long_row, *long_first;
     const void *val, *Wh, *att;
     unsigned h_bytes, ld_bytes;
     const float *s1, *fill;
