@@ -220,3 +220,49 @@ def test_full_size_exact_mode_dense_stage_bits(workload, oracle):
     assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
     plain = ops.xw_dense(D1, W2t)[rows].cpu().numpy()
     assert (plain.view(np.uint16) != got.view(np.uint16)).mean() > 0.02      # an observable arithmetic, as in the CSR stage
+
+
+def test_full_size_rmat_gat_aggregate_properties():
+    """The GAT aggregate on the full-size power-law graph (4.2 M nodes, ~100 M edges, hubs of 10^5 entries through tasks,
+    degree order, the one-piece tail), one head of 64 columns -- **parity unpinned** like all of GAT; properties that need
+    no CPU pass: a table whose rows are all the same vector comes back as that vector on every row with a live entry
+    (softmax weights sum to 1, whatever the scores) and as 0 elsewhere; the one-walk form (csrc/gat_fused.hip) and the
+    two stages (scores gathered per edge, weights through memory) agree on every row of a random table; the same bits on
+    a second run."""
+    import bench
+    from sgracex1_amd import _lib, graphs, ops
+    wl = bench.WORKLOADS["s100m-rmat"]
+    A, _X, _W1t, _W2t = bench.make_inputs(torch, graphs, ops, wl, 0, 1, dev)
+    del _X
+    torch.cuda.empty_cache()
+    n, P = A.n_rows, 64
+    assert A.gat_plan.long_rows > 1000 and A.gat_plan.reordered
+    g = torch.Generator(device=dev)
+    g.manual_seed(31)
+    att = ((torch.rand(2 * P, generator=g, device=dev) * 2 - 1) * 0.3).half()
+    deg = (A.rowptr[1:] - A.rowptr[:-1]).long()
+    row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    # (the generator gives every node a self loop: some rows lose all their entries to the mask here, a hub among them)
+    masked = torch.zeros(n, dtype=torch.bool, device=dev)
+    masked[torch.arange(5, n, 1001, device=dev)] = True
+    masked[torch.topk(deg, 3).indices[-1]] = True
+    val = torch.where(masked[row], torch.zeros_like(A.val), A.val)
+    A = ops.Csr(A.rowptr, A.col, val, A.n_cols, A.plan)
+    live = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, row, (val.float() > 0).long()) > 0
+    assert torch.equal(live, ~masked)
+    del row, val
+    v = (torch.rand(P, generator=g, device=dev) * 2 - 1).half()
+    same = v.expand(n, P).contiguous()
+    D = ops.gat_aggregate(A, same, att, relu=False, fill_dead_rows=False)
+    assert (D[live].float() - v.float()).abs().max() <= 2.0 ** -10 * float(v.float().abs().max())     # one binary16 ulp of the largest entry
+    assert not D[~live].any() and int((~live).sum()) > 0
+    del same, D
+    Wh = (torch.rand((n, P), generator=g, device=dev) - 0.4).half()
+    one_walk = ops.gat_aggregate(A, Wh, att, relu=True, fill_dead_rows=False)
+    assert torch.equal(ops.gat_aggregate(A, Wh, att, relu=True, fill_dead_rows=False), one_walk)
+    with _lib.tuning(SGX_GAT_FUSED="0"):
+        two_stage = ops.gat_aggregate(A, Wh, att, relu=True, fill_dead_rows=False)
+    assert not torch.equal(one_walk, two_stage)                                 # (two forms ran)
+    torch.testing.assert_close(one_walk.float(), two_stage.float(), rtol=2e-3, atol=1e-3)
+    hubs = torch.topk(deg, 64).indices
+    assert int(deg[hubs].min()) > 1000 and torch.isfinite(one_walk[hubs].float()).all()
