@@ -26,6 +26,9 @@ __device__ __forceinline__ float dpp_swap(float v)
 template <int HL>
 __device__ __forceinline__ float head_sum(float v, int lane)
 {
+    // v comes out of Dot's inline assembly, and a DPP read wants two wait states behind the VALU write of its source: the
+    // compiler keeps that distance for instructions it knows, not for ones inside an asm statement
+    if constexpr (HL >= 2) asm volatile("s_nop 1" : "+v"(v));
     if constexpr (HL >= 2) v += dpp_swap<0xB1>(v);           // quad_perm [1,0,3,2]
     if constexpr (HL >= 4) v += dpp_swap<0x4E>(v);           // quad_perm [2,3,0,1]
     if constexpr (HL >= 8) v += dpp_swap<0x141>(v);          // row_half_mirror: the other quad of the 8
